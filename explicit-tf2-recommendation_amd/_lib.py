@@ -1,0 +1,77 @@
+"""ctypes binding of csrc/libmi355rec.so (the C ABI declared in include/mi355rec.h).
+
+The HIP library is the product: there is NO fallback.  If the shared object is missing or a symbol the
+header declares cannot be resolved, importing this module raises -- build it with
+``python -c "import __graft_entry__ as g; g.build()"`` (or ``csrc/build.sh``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmi355rec.so")
+
+p, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# symbol -> (restype, argtypes); must list every function of include/mi355rec.h
+SIGNATURES = {
+    "rec_version": (i32, []),
+    "rec_index_pack_i64": (i32, [p, i32, i64, p, i64, i64, p]),
+    "rec_emb_gather_f32": (i32, [p, i64, i32, p, i64, p, p, p]),
+    "rec_emb_fm_fwd_f32": (i32, [p, p, p, i64, i32, p, i64, i32, p, p, p, p, p, p]),
+    "rec_emb_fm_bwd_vals_f32": (i32, [p, i64, i32, p, i64, i32, p, p, p, p, p, p]),
+    "rec_dedup_workspace_bytes": (sz, [i64]),
+    "rec_dedup_plan_i64": (i32, [p, i64, i64, p, p, p, p, p, sz, p]),
+    "rec_segment_sum_f32": (i32, [p, i32, p, p, i64, i32, p, p]),
+    "rec_gemm_f32": (i32, [i32, i32, i64, i64, i64, p, i64, p, i64, p, i64, i32, p, p, i64, p, i64, i32, p, p]),
+    "rec_act_bwd_f32": (i32, [i32, p, p, p, i64, p]),
+    "rec_colsum_f32": (i32, [p, i64, i64, i64, p, p]),
+    "rec_axpby_f32": (i32, [f32, p, f32, p, i64, p]),
+    "rec_copy_cols_f32": (i32, [p, i64, p, i64, i64, i64, p]),
+    "rec_crossnet_vec_fwd_f32": (i32, [p, i64, i32, i32, p, p, p, p, p]),
+    "rec_crossnet_vec_bwd_workspace_bytes": (sz, [i64, i32, i32]),
+    "rec_crossnet_vec_bwd_f32": (i32, [p, i64, i32, i32, p, p, p, p, p, p, p, p]),
+    "rec_cosine_fwd_f32": (i32, [p, p, i64, i32, p, p]),
+    "rec_cosine_bwd_f32": (i32, [p, p, i64, i32, p, p, p, p]),
+    "rec_bce_fwd_bwd_f32": (i32, [p, p, i64, p, p, p, p]),
+    "rec_adam_dense_f32": (i32, [p, p, p, p, i64, i64, f32, f32, f32, f32, p]),
+    "rec_adam_sparse_keras_f32": (i32, [p, p, p, i64, i32, p, p, p, i64, p, i64, f32, f32, f32, f32, p]),
+    "rec_adam_rows_f32": (i32, [p, p, p, i64, i32, p, p, p, i64, i64, f32, f32, f32, f32, p]),
+    "rec_shard_bucketize_workspace_bytes": (sz, [i64, i32]),
+    "rec_shard_bucketize_i64": (i32, [p, i64, i64, i32, p, p, p, p, p, sz, p]),
+    "rec_permute_rows_f32": (i32, [p, p, i64, i32, i32, p, p]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s not found: the HIP extension is required (no CPU fallback exists). "
+            "Build it with __graft_entry__.build() or csrc/build.sh" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # header / library out of sync
+            raise ImportError("libmi355rec.so does not export %s: rebuild it" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class RecError(RuntimeError):
+    pass
+
+
+def check(status, what):
+    if status == 0:
+        return
+    if status == -1:
+        raise ValueError("%s: invalid argument" % what)
+    if status == -2:
+        raise NotImplementedError("%s: unsupported configuration" % what)
+    if status == -3:
+        raise RecError("%s: workspace too small" % what)
+    raise RecError("%s: hipError_t %d" % (what, status))

@@ -1,0 +1,233 @@
+// De-duplication of an IndexedSlices gradient: sort lookups by id, find the runs, sum the rows of a run.
+// Replaces tf.unique + unsorted_segment_sum inside Keras' optimizer (2.FM/ModelManager.py:178-179) and the
+// tf.unique of 5.DIN/ModelManager.py:185-186.  Deterministic: a stable radix sort puts the rows of one id
+// in ascending position order and every run is summed in that order -- no float atomics.
+//
+// The key/position radix sort is rocPRIM's device primitive (header-only, compiled here for gfx950); the
+// run detection, compaction and the segment sums are hand-written.
+#include "common.h"
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace {
+
+constexpr int TILE = 1024;  // sorted keys per workgroup in the run-detection kernels (256 threads x 4)
+
+struct Layout {
+  size_t keys_in, keys_out, pos_in, tile_heads, sort_tmp, sort_tmp_bytes, total;
+};
+
+inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+Layout make_layout(int64_t n) {
+  Layout L;
+  size_t off = 0;
+  L.keys_in = off; off = align256(off + sizeof(uint32_t) * n);
+  L.keys_out = off; off = align256(off + sizeof(uint32_t) * n);
+  L.pos_in = off; off = align256(off + sizeof(int32_t) * n);
+  L.tile_heads = off; off = align256(off + sizeof(int32_t) * (size_t)(ceil_div64(n, TILE) + 1));
+  size_t tmp = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr,
+                            (int32_t*)nullptr, (size_t)n, 0, 32, (hipStream_t)0);
+  L.sort_tmp = off;
+  L.sort_tmp_bytes = tmp;
+  off = align256(off + tmp);
+  L.total = off;
+  return L;
+}
+
+__global__ __launch_bounds__(256) void prep_keys_kernel(const int64_t* __restrict__ ids, int64_t n,
+                                                        uint32_t* __restrict__ keys, int32_t* __restrict__ pos) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  keys[t] = (uint32_t)ids[t];
+  pos[t] = (int32_t)t;
+}
+
+__device__ __forceinline__ int block_sum_256(int v, int* sh) {
+  // sh: 4 ints.  Returns the block total to every thread.
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[wave] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void count_heads_kernel(const uint32_t* __restrict__ keys, int64_t n,
+                                                          int32_t* __restrict__ tile_heads) {
+  __shared__ int sh[4];
+  int64_t base = (int64_t)blockIdx.x * TILE;
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < TILE / 256; ++k) {
+    int64_t i = base + threadIdx.x + k * 256;
+    if (i < n) cnt += (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+  }
+  int tot = block_sum_256(cnt, sh);
+  if (threadIdx.x == 0) tile_heads[blockIdx.x] = tot;
+}
+
+// One workgroup per tile of sorted keys: global rank of every run head = heads in earlier tiles (summed
+// redundantly by each workgroup, a few hundred ints) + exclusive rank inside the tile.
+__global__ __launch_bounds__(256) void finalize_kernel(const uint32_t* __restrict__ keys, int64_t n,
+                                                       const int32_t* __restrict__ tile_heads, int n_tiles,
+                                                       int64_t* __restrict__ uniq_ids,
+                                                       int32_t* __restrict__ seg_start,
+                                                       int64_t* __restrict__ n_uniq) {
+  __shared__ int sh[4];
+  __shared__ int wave_tot[4];
+  int before = 0, all = 0;
+  for (int t = threadIdx.x; t < n_tiles; t += 256) {
+    int h = tile_heads[t];
+    all += h;
+    if (t < (int)blockIdx.x) before += h;
+  }
+  before = block_sum_256(before, sh);
+  all = block_sum_256(all, sh);
+  // thread owns 4 consecutive sorted positions
+  int64_t i0 = (int64_t)blockIdx.x * TILE + (int64_t)threadIdx.x * 4;
+  int flag[4];
+  uint32_t key[4];
+  int mine = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int64_t i = i0 + k;
+    flag[k] = 0;
+    key[k] = 0;
+    if (i < n) {
+      key[k] = keys[i];
+      flag[k] = (i == 0 || key[k] != keys[i - 1]) ? 1 : 0;
+    }
+    mine += flag[k];
+  }
+  // exclusive scan of `mine` over the 256 threads
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = mine;
+  for (int o = 1; o < 64; o <<= 1) {
+    int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  __syncthreads();
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int woff = 0;
+  for (int q = 0; q < wave; ++q) woff += wave_tot[q];
+  int rank = before + woff + incl - mine;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int64_t i = i0 + k;
+    if (i < n && flag[k]) {
+      uniq_ids[rank] = (int64_t)key[k];
+      seg_start[rank] = (int32_t)i;
+      ++rank;
+    }
+  }
+  // tail padding: slots >= n_uniq become empty runs of a valid id (keys[0] = the smallest id)
+  uint32_t pad = keys[0];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int64_t i = i0 + k;
+    if (i < n && i >= all) uniq_ids[i] = (int64_t)pad;
+    if (i < n && i + 1 >= all) seg_start[i + 1] = (int32_t)n;  // covers seg_start[n_uniq .. n]
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *n_uniq = all;
+  }
+}
+
+// One lane group (LPR lanes x float4) per unique id; rows of the run are added in sorted (= position) order.
+__global__ __launch_bounds__(256) void segsum_vec_kernel(const float4* __restrict__ vals, int lpr,
+                                                         const int32_t* __restrict__ perm,
+                                                         const int32_t* __restrict__ seg_start, int64_t n,
+                                                         int32_t row_div, float4* __restrict__ out) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * lpr) return;
+  int64_t u = t / lpr;
+  int c = (int)(t - u * lpr);
+  int s0 = seg_start[u], s1 = seg_start[u + 1];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = s0; s < s1; ++s) {
+    int64_t src = perm[s] / row_div;
+    float4 v = vals[src * lpr + c];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  out[t] = acc;
+}
+
+__global__ __launch_bounds__(256) void segsum_scalar_kernel(const float* __restrict__ vals, int E,
+                                                            const int32_t* __restrict__ perm,
+                                                            const int32_t* __restrict__ seg_start, int64_t n,
+                                                            int32_t row_div, float* __restrict__ out) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * E) return;
+  int64_t u = t / E;
+  int d = (int)(t - u * E);
+  int s0 = seg_start[u], s1 = seg_start[u + 1];
+  float acc = 0.f;
+  for (int s = s0; s < s1; ++s) {
+    int64_t src = perm[s] / row_div;
+    acc += vals[src * E + d];
+  }
+  out[t] = acc;
+}
+
+}  // namespace
+
+extern "C" size_t rec_dedup_workspace_bytes(int64_t n) {
+  if (n <= 0) return 256;
+  return make_layout(n).total;
+}
+
+extern "C" int rec_dedup_plan_i64(const int64_t* ids, int64_t n, int64_t V, int64_t* uniq_ids,
+                                  int32_t* seg_start, int32_t* perm, int64_t* n_uniq, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  if (!ids || !uniq_ids || !seg_start || !perm || !n_uniq || !workspace || n < 0 || V <= 0) return REC_E_ARG;
+  if (n >= (int64_t(1) << 31) || V > (int64_t(1) << 32)) return REC_E_UNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  if (n == 0) {
+    hipError_t e = hipMemsetAsync(n_uniq, 0, sizeof(int64_t), st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(seg_start, 0, sizeof(int32_t), st);
+    return (int)e;
+  }
+  Layout L = make_layout(n);
+  if (workspace_bytes < L.total) return REC_E_WORKSPACE;
+  char* ws = (char*)workspace;
+  uint32_t* keys_in = (uint32_t*)(ws + L.keys_in);
+  uint32_t* keys_out = (uint32_t*)(ws + L.keys_out);
+  int32_t* pos_in = (int32_t*)(ws + L.pos_in);
+  int32_t* tile_heads = (int32_t*)(ws + L.tile_heads);
+  hipLaunchKernelGGL(prep_keys_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, st, ids, n, keys_in,
+                     pos_in);
+  REC_LAUNCH_CHECK();
+  unsigned end_bit = 1;
+  while (end_bit < 32 && (int64_t(1) << end_bit) < V) ++end_bit;
+  size_t tmp = L.sort_tmp_bytes;
+  hipError_t e = rocprim::radix_sort_pairs(ws + L.sort_tmp, tmp, keys_in, keys_out, pos_in, perm, (size_t)n, 0u,
+                                           end_bit, st);
+  if (e != hipSuccess) return (int)e;
+  int n_tiles = (int)ceil_div64(n, TILE);
+  hipLaunchKernelGGL(count_heads_kernel, dim3(n_tiles), dim3(256), 0, st, keys_out, n, tile_heads);
+  REC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(finalize_kernel, dim3(n_tiles), dim3(256), 0, st, keys_out, n, tile_heads, n_tiles,
+                     uniq_ids, seg_start, n_uniq);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_segment_sum_f32(const float* vals, int E, const int32_t* perm, const int32_t* seg_start,
+                                   int64_t n, int32_t row_div, float* out, void* stream) {
+  if (!vals || !perm || !seg_start || !out || E <= 0 || n < 0 || row_div <= 0) return REC_E_ARG;
+  if (n == 0) return REC_OK;
+  if (E % 4 == 0) {
+    int lpr = E / 4;
+    hipLaunchKernelGGL(segsum_vec_kernel, dim3((unsigned)ceil_div64(n * lpr, 256)), dim3(256), 0,
+                       as_stream(stream), (const float4*)vals, lpr, perm, seg_start, n, row_div, (float4*)out);
+  } else {
+    hipLaunchKernelGGL(segsum_scalar_kernel, dim3((unsigned)ceil_div64(n * E, 256)), dim3(256), 0,
+                       as_stream(stream), vals, E, perm, seg_start, n, row_div, out);
+  }
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}

@@ -1,0 +1,577 @@
+// Row-local and elementwise kernels of the path (all HBM-bound; one pass over their operands):
+//   CrossLayer vector mode fwd/bwd        3.DCN/CustomLayers.py:195-203      (K7)
+//   two-tower cosine score fwd/bwd        2.FM/CustomLayers.py:233-234       (K10)
+//   Keras BinaryCrossentropy fwd+bwd      2.FM/ModelManager.py:100,175       (K11)
+//   Keras Adam dense / sparse (=dense sweep) / lazy rows   2.FM/ModelManager.py:104,178-179  (K12)
+//   activation backward, column sums, axpby, column-block copies (dense backward plumbing)
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// small elementwise helpers
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_bwd_kernel(int act, const float* __restrict__ post,
+                                                      const float* __restrict__ dpost, float* __restrict__ dpre,
+                                                      int64_t n) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  float y = post[t], g = dpost[t];
+  switch (act) {
+    case REC_ACT_RELU: g = y > 0.f ? g : 0.f; break;
+    case REC_ACT_SIGMOID: g = g * y * (1.f - y); break;
+    case REC_ACT_TANH: g = g * (1.f - y * y); break;
+    default: break;
+  }
+  dpre[t] = g;
+}
+
+// out[j] = sum_i X[i,j]: 32 columns x 8 row lanes per workgroup, fixed summation order.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int64_t M, int64_t N, int64_t ldx,
+                                                     float* __restrict__ out) {
+  __shared__ float sh[8][33];
+  int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+  int64_t col = (int64_t)blockIdx.x * 32 + c;
+  float acc = 0.f;
+  if (col < N)
+    for (int64_t i = r; i < M; i += 8) acc += X[i * ldx + col];
+  sh[r][c] = acc;
+  __syncthreads();
+  if (r == 0 && col < N) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += sh[q][c];
+    out[col] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(float a, const float* __restrict__ x, float b,
+                                                    float* __restrict__ y, int64_t n) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  y[t] = (b == 0.f) ? a * x[t] : a * x[t] + b * y[t];
+}
+
+__global__ __launch_bounds__(256) void copy_cols_kernel(const float* __restrict__ src, int64_t lds_,
+                                                        float* __restrict__ dst, int64_t ldd, int64_t rows,
+                                                        int64_t w) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= rows * w) return;
+  int64_t r = t / w, c = t - r * w;
+  dst[r * ldd + c] = src[r * lds_ + c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7 CrossNet vector mode: one wave per example row, the row lives in registers across all L layers
+// (x0 read once, y written once).  lane owns dims lane, lane+64, ...; D <= 64*MAXJ.
+// ------------------------------------------------------------------------------------------------
+constexpr int MAXJ = 16;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void cross_vec_fwd_kernel(const float* __restrict__ x0, int64_t B, int D, int L,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            float* __restrict__ y, float* __restrict__ xs) {
+  int lane = threadIdx.x & 63;
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  float a0[MAXJ], xl[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    int d = lane + 64 * j;
+    a0[j] = d < D ? x0[row * D + d] : 0.f;
+    xl[j] = a0[j];
+  }
+  for (int l = 0; l < L; ++l) {
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      int d = lane + 64 * j;
+      if (d < D) {
+        if (xs) xs[((int64_t)l * B + row) * D + d] = xl[j];
+        dot += xl[j] * w[l * D + d];
+      }
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      int d = lane + 64 * j;
+      if (d < D) xl[j] = a0[j] * dot + b[l * D + d] + xl[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    int d = lane + 64 * j;
+    if (d < D) y[row * D + d] = xl[j];
+  }
+}
+
+// backward, one launch per layer (reverse order): rows are split over `nchunk` workgroups, each wave walks
+// its rows with the layer's w in registers, updates the running gradient g and gx0 in place and keeps the
+// dw/db partial sums of its rows in registers; a second kernel adds the per-wave partials in a fixed order.
+__global__ __launch_bounds__(256) void cross_vec_bwd_layer_kernel(
+    const float* __restrict__ x0, int64_t B, int D, const float* __restrict__ wl, const float* __restrict__ xl_saved,
+    float* __restrict__ g /* in/out [B,D] */, float* __restrict__ gx0 /* accum [B,D] */,
+    float* __restrict__ part /* [nchunk, 2, D] */, int rows_per_wg, int first_layer) {
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t r_begin = (int64_t)blockIdx.x * rows_per_wg;
+  int64_t r_end = r_begin + rows_per_wg < B ? r_begin + rows_per_wg : B;
+  float dw[MAXJ], db[MAXJ], wv[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    int d = lane + 64 * j;
+    dw[j] = 0.f;
+    db[j] = 0.f;
+    wv[j] = d < D ? wl[d] : 0.f;
+  }
+  for (int64_t row = r_begin + wave; row < r_end; row += 4) {
+    float gv[MAXJ], xv[MAXJ], a0[MAXJ];
+    float s = 0.f, t = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      int d = lane + 64 * j;
+      bool ok = d < D;
+      gv[j] = ok ? g[row * D + d] : 0.f;
+      xv[j] = ok ? xl_saved[row * D + d] : 0.f;
+      a0[j] = ok ? x0[row * D + d] : 0.f;
+      s += xv[j] * wv[j];
+      t += gv[j] * a0[j];
+    }
+    s = wave_sum(s);
+    t = wave_sum(t);
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      int d = lane + 64 * j;
+      if (d < D) {
+        dw[j] += t * xv[j];
+        db[j] += gv[j];
+        float acc = first_layer ? 0.f : gx0[row * D + d];
+        gx0[row * D + d] = acc + gv[j] * s;
+        g[row * D + d] = gv[j] + t * wv[j];
+      }
+    }
+  }
+  // per-wave partials -> global (wave-major); a second kernel adds them in a fixed order
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    int d = lane + 64 * j;
+    if (d < D) {
+      int64_t slot = (int64_t)blockIdx.x * 4 + wave;
+      part[(slot * 2 + 0) * D + d] = dw[j];
+      part[(slot * 2 + 1) * D + d] = db[j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cross_vec_bwd_reduce_kernel(const float* __restrict__ part, int nslot, int D,
+                                                                   float* __restrict__ dw, float* __restrict__ db) {
+  int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= 2 * D) return;
+  int which = t / D, d = t - which * D;
+  float acc = 0.f;
+  for (int s = 0; s < nslot; ++s) acc += part[((int64_t)s * 2 + which) * D + d];
+  (which == 0 ? dw : db)[d] = acc;
+}
+
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                          int64_t n) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < n) y[t] += x[t];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K10 cosine
+// ------------------------------------------------------------------------------------------------
+template <int GW>
+__global__ __launch_bounds__(256) void cosine_fwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                         int64_t B, int d, float* __restrict__ out) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t row = t / GW;
+  int c = (int)(t % GW);
+  if (row >= B) return;
+  float uu = 0.f, vv = 0.f, uv = 0.f;
+  for (int k = c; k < d; k += GW) {
+    float a = u[row * d + k], b = v[row * d + k];
+    uu += a * a;
+    vv += b * b;
+    uv += a * b;
+  }
+  uu = group_sum<GW>(uu);
+  vv = group_sum<GW>(vv);
+  uv = group_sum<GW>(uv);
+  if (c == 0) {
+    float ru = rsqrtf(fmaxf(uu, 1e-12f)), rv = rsqrtf(fmaxf(vv, 1e-12f));
+    out[row] = (1.f - uv * ru * rv) * 0.5f;
+  }
+}
+
+template <int GW>
+__global__ __launch_bounds__(256) void cosine_bwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                         int64_t B, int d, const float* __restrict__ gout,
+                                                         float* __restrict__ gu, float* __restrict__ gv) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t row = t / GW;
+  int c = (int)(t % GW);
+  if (row >= B) return;
+  float uu = 0.f, vv = 0.f, uv = 0.f;
+  for (int k = c; k < d; k += GW) {
+    float a = u[row * d + k], b = v[row * d + k];
+    uu += a * a;
+    vv += b * b;
+    uv += a * b;
+  }
+  uu = group_sum<GW>(uu);
+  vv = group_sum<GW>(vv);
+  uv = group_sum<GW>(uv);
+  // out = (1 - c)/2, c = u_hat.v_hat ; dc/du = (v_hat - c u_hat)/|u|  (zero where the norm is clamped)
+  float ru = rsqrtf(fmaxf(uu, 1e-12f)), rv = rsqrtf(fmaxf(vv, 1e-12f));
+  float cs = uv * ru * rv;
+  float gc = -0.5f * gout[row];
+  bool cu = uu > 1e-12f, cv = vv > 1e-12f;
+  for (int k = c; k < d; k += GW) {
+    float a = u[row * d + k], b = v[row * d + k];
+    float uh = a * ru, vh = b * rv;
+    // clamped norm: u_hat = u * 1e6 is linear in u, d(u_hat)/du = 1e6 (no projection term)
+    gu[row * d + k] = cu ? gc * (vh - cs * uh) * ru : gc * vh * ru;
+    gv[row * d + k] = cv ? gc * (uh - cs * vh) * rv : gc * uh * rv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K11 BCE: one workgroup of 1024 threads, fixed-order tree => deterministic loss
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ y, const float* __restrict__ p, int64_t n,
+                                                   float* __restrict__ loss, float* __restrict__ dp,
+                                                   float* __restrict__ dz) {
+  __shared__ float sh[16];
+  const float eps = 1e-7f;
+  float inv_n = 1.0f / (float)n;
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    float yy = y[i], pp = p[i];
+    float pc = fminf(fmaxf(pp, eps), 1.f - eps);
+    acc += -(yy * logf(pc + eps) + (1.f - yy) * logf(1.f - pc + eps));
+    if (dp || dz) {
+      float inside = (pp >= eps && pp <= 1.f - eps) ? 1.f : 0.f;
+      float g = -(yy / (pc + eps) - (1.f - yy) / (1.f - pc + eps)) * inside * inv_n;
+      if (dp) dp[i] = g;
+      if (dz) dz[i] = g * pp * (1.f - pp);
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += sh[q];
+    if (loss) *loss = s * inv_n;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K12 Adam
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ var, float* __restrict__ m,
+                                                         float* __restrict__ v, const float* __restrict__ g, int64_t n,
+                                                         float lr_t, float b1, float b2, float eps) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  float gg = g[t];
+  float mm = m[t], vv = v[t];
+  mm = mm + (gg - mm) * (1.f - b1);
+  vv = vv + (gg * gg - vv) * (1.f - b2);
+  m[t] = mm;
+  v[t] = vv;
+  var[t] = var[t] - lr_t * mm / (sqrtf(vv) + eps);
+}
+
+// touched rows: new (var, m, v) computed from the ORIGINAL state into `side` [cap, 3, E]
+__global__ __launch_bounds__(256) void adam_rows_side_kernel(const float* __restrict__ var, const float* __restrict__ m,
+                                                             const float* __restrict__ v, int64_t V, int E,
+                                                             const int64_t* __restrict__ ids,
+                                                             const float* __restrict__ g, const int64_t* n_uniq,
+                                                             int64_t cap, float* __restrict__ side, float lr_t,
+                                                             float b1, float b2, float eps) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= cap * E) return;
+  int64_t u = t / E;
+  int d = (int)(t - u * E);
+  if (u >= *n_uniq) return;
+  int64_t id = ids[u];
+  if ((uint64_t)id >= (uint64_t)V) return;
+  float gg = g[t];
+  float mm = m[id * E + d] * b1 + gg * (1.f - b1);
+  float vv = v[id * E + d] * b2 + gg * gg * (1.f - b2);
+  side[(u * 3 + 0) * E + d] = var[id * E + d] - lr_t * mm / (sqrtf(vv) + eps);
+  side[(u * 3 + 1) * E + d] = mm;
+  side[(u * 3 + 2) * E + d] = vv;
+}
+
+// all rows: the untouched-row form of the dense sweep (streaming, float4 when possible)
+__global__ __launch_bounds__(256) void adam_sweep_vec_kernel(float4* __restrict__ var, float4* __restrict__ m,
+                                                             float4* __restrict__ v, int64_t n4, float lr_t, float b1,
+                                                             float b2, float eps) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * 256;
+  for (; t < n4; t += stride) {
+    float4 mm = m[t], vv = v[t], x = var[t];
+    mm.x *= b1; mm.y *= b1; mm.z *= b1; mm.w *= b1;
+    vv.x *= b2; vv.y *= b2; vv.z *= b2; vv.w *= b2;
+    x.x -= lr_t * mm.x / (sqrtf(vv.x) + eps);
+    x.y -= lr_t * mm.y / (sqrtf(vv.y) + eps);
+    x.z -= lr_t * mm.z / (sqrtf(vv.z) + eps);
+    x.w -= lr_t * mm.w / (sqrtf(vv.w) + eps);
+    m[t] = mm;
+    v[t] = vv;
+    var[t] = x;
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_sweep_scalar_kernel(float* __restrict__ var, float* __restrict__ m,
+                                                                float* __restrict__ v, int64_t n, float lr_t, float b1,
+                                                                float b2, float eps) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * 256;
+  for (; t < n; t += stride) {
+    float mm = m[t] * b1, vv = v[t] * b2;
+    m[t] = mm;
+    v[t] = vv;
+    var[t] = var[t] - lr_t * mm / (sqrtf(vv) + eps);
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_rows_patch_kernel(float* __restrict__ var, float* __restrict__ m,
+                                                              float* __restrict__ v, int64_t V, int E,
+                                                              const int64_t* __restrict__ ids, const int64_t* n_uniq,
+                                                              int64_t cap, const float* __restrict__ side) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= cap * E) return;
+  int64_t u = t / E;
+  int d = (int)(t - u * E);
+  if (u >= *n_uniq) return;
+  int64_t id = ids[u];
+  if ((uint64_t)id >= (uint64_t)V) return;
+  var[id * E + d] = side[(u * 3 + 0) * E + d];
+  m[id * E + d] = side[(u * 3 + 1) * E + d];
+  v[id * E + d] = side[(u * 3 + 2) * E + d];
+}
+
+__global__ __launch_bounds__(256) void adam_rows_lazy_kernel(float* __restrict__ var, float* __restrict__ m,
+                                                             float* __restrict__ v, int64_t V, int E,
+                                                             const int64_t* __restrict__ ids, const float* __restrict__ g,
+                                                             const int64_t* n_uniq, int64_t cap, float lr_t, float b1,
+                                                             float b2, float eps) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= cap * E) return;
+  int64_t u = t / E;
+  int d = (int)(t - u * E);
+  if (u >= *n_uniq) return;
+  int64_t id = ids[u];
+  if ((uint64_t)id >= (uint64_t)V) return;
+  float gg = g[t];
+  float mm = m[id * E + d] * b1 + gg * (1.f - b1);
+  float vv = v[id * E + d] * b2 + gg * gg * (1.f - b2);
+  m[id * E + d] = mm;
+  v[id * E + d] = vv;
+  var[id * E + d] = var[id * E + d] - lr_t * mm / (sqrtf(vv) + eps);
+}
+
+inline float adam_lr_t(float lr, float b1, float b2, int64_t t) {
+  // float32 arithmetic as Keras does (tf.pow on float32 scalars)
+  float b1p = powf(b1, (float)t), b2p = powf(b2, (float)t);
+  return lr * sqrtf(1.f - b2p) / (1.f - b1p);
+}
+
+}  // namespace
+
+extern "C" int rec_version(void) { return 100; }
+
+extern "C" int rec_act_bwd_f32(int act, const float* post, const float* dpost, float* dpre, int64_t n,
+                               void* stream) {
+  if (!post || !dpost || !dpre || n < 0 || act < REC_ACT_NONE || act > REC_ACT_TANH) return REC_E_ARG;
+  if (n == 0) return REC_OK;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, as_stream(stream), act, post,
+                     dpost, dpre, n);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx, float* out, void* stream) {
+  if (!X || !out || M < 0 || N <= 0 || ldx < N) return REC_E_ARG;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div64(N, 32)), dim3(256), 0, as_stream(stream), X, M, N, ldx,
+                     out);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_axpby_f32(float a, const float* x, float b, float* y, int64_t n, void* stream) {
+  if (!x || !y || n < 0) return REC_E_ARG;
+  if (n == 0) return REC_OK;
+  hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, as_stream(stream), a, x, b, y, n);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_copy_cols_f32(const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t rows, int64_t w,
+                                 void* stream) {
+  if (!src || !dst || rows < 0 || w < 0 || lds_ < w || ldd < w) return REC_E_ARG;
+  if (rows * w == 0) return REC_OK;
+  hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)ceil_div64(rows * w, 256)), dim3(256), 0, as_stream(stream), src,
+                     lds_, dst, ldd, rows, w);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_crossnet_vec_fwd_f32(const float* x0, int64_t B, int D, int L, const float* w, const float* b,
+                                        float* y, float* xs, void* stream) {
+  if (!x0 || !w || !b || !y || B < 0 || D <= 0 || L < 0) return REC_E_ARG;
+  if (D > 64 * MAXJ) return REC_E_UNSUPPORTED;
+  if (B == 0) return REC_OK;
+  hipLaunchKernelGGL(cross_vec_fwd_kernel, dim3((unsigned)ceil_div64(B, 4)), dim3(256), 0, as_stream(stream), x0, B, D,
+                     L, w, b, y, xs);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+static inline int cross_bwd_chunks(int64_t B) {
+  int64_t c = ceil_div64(B, 64);  // >= 64 rows per workgroup
+  return (int)(c < 1 ? 1 : (c > 512 ? 512 : c));
+}
+
+extern "C" size_t rec_crossnet_vec_bwd_workspace_bytes(int64_t B, int D, int L) {
+  (void)L;
+  size_t g = sizeof(float) * (size_t)B * D;                               // running gradient g
+  size_t part = sizeof(float) * (size_t)cross_bwd_chunks(B) * 4 * 2 * D;  // per-wave dw/db partials
+  return g + part + 512;
+}
+
+extern "C" int rec_crossnet_vec_bwd_f32(const float* x0, int64_t B, int D, int L, const float* w, const float* xs,
+                                        const float* gy, float* gx0, float* dw, float* db, void* workspace,
+                                        void* stream) {
+  if (!x0 || !w || !xs || !gy || !gx0 || !dw || !db || !workspace || B < 0 || D <= 0 || L < 0) return REC_E_ARG;
+  if (D > 64 * MAXJ) return REC_E_UNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  if (B == 0) return REC_OK;
+  float* g = (float*)workspace;
+  float* part = g + (size_t)B * D;
+  int nchunk = cross_bwd_chunks(B);
+  int rows_per_wg = (int)ceil_div64(B, nchunk);
+  hipError_t e = hipMemcpyAsync(g, gy, sizeof(float) * (size_t)B * D, hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) return (int)e;
+  if (L == 0) {
+    e = hipMemcpyAsync(gx0, gy, sizeof(float) * (size_t)B * D, hipMemcpyDeviceToDevice, st);
+    return (int)e;
+  }
+  for (int l = L - 1; l >= 0; --l) {
+    hipLaunchKernelGGL(cross_vec_bwd_layer_kernel, dim3(nchunk), dim3(256), 0, st, x0, B, D, w + (size_t)l * D,
+                       xs + (size_t)l * B * D, g, gx0, part, rows_per_wg, l == L - 1 ? 1 : 0);
+    REC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(cross_vec_bwd_reduce_kernel, dim3((unsigned)ceil_div64(2 * D, 256)), dim3(256), 0, st, part,
+                       nchunk * 4, D, dw + (size_t)l * D, db + (size_t)l * D);
+    REC_LAUNCH_CHECK();
+  }
+  // x_0 is also the input of layer 0: gx0 += g
+  hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)ceil_div64(B * D, 256)), dim3(256), 0, st, gx0, g,
+                     (int64_t)B * D);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+#define COS_DISPATCH(KERN, ...)                                                                                  \
+  do {                                                                                                           \
+    if (d <= 1) hipLaunchKernelGGL(KERN<1>, dim3((unsigned)ceil_div64(B * 1, 256)), dim3(256), 0, st, __VA_ARGS__);      \
+    else if (d <= 2) hipLaunchKernelGGL(KERN<2>, dim3((unsigned)ceil_div64(B * 2, 256)), dim3(256), 0, st, __VA_ARGS__); \
+    else if (d <= 4) hipLaunchKernelGGL(KERN<4>, dim3((unsigned)ceil_div64(B * 4, 256)), dim3(256), 0, st, __VA_ARGS__); \
+    else if (d <= 8) hipLaunchKernelGGL(KERN<8>, dim3((unsigned)ceil_div64(B * 8, 256)), dim3(256), 0, st, __VA_ARGS__); \
+    else if (d <= 16) hipLaunchKernelGGL(KERN<16>, dim3((unsigned)ceil_div64(B * 16, 256)), dim3(256), 0, st, __VA_ARGS__); \
+    else if (d <= 32) hipLaunchKernelGGL(KERN<32>, dim3((unsigned)ceil_div64(B * 32, 256)), dim3(256), 0, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERN<64>, dim3((unsigned)ceil_div64(B * 64, 256)), dim3(256), 0, st, __VA_ARGS__);           \
+  } while (0)
+
+extern "C" int rec_cosine_fwd_f32(const float* u, const float* i, int64_t B, int d, float* out, void* stream) {
+  if (!u || !i || !out || B < 0 || d <= 0) return REC_E_ARG;
+  if (B == 0) return REC_OK;
+  hipStream_t st = as_stream(stream);
+  COS_DISPATCH(cosine_fwd_kernel, u, i, B, d, out);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_cosine_bwd_f32(const float* u, const float* i, int64_t B, int d, const float* gout, float* gu,
+                                  float* gi, void* stream) {
+  if (!u || !i || !gout || !gu || !gi || B < 0 || d <= 0) return REC_E_ARG;
+  if (B == 0) return REC_OK;
+  hipStream_t st = as_stream(stream);
+  COS_DISPATCH(cosine_bwd_kernel, u, i, B, d, gout, gu, gi);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_bce_fwd_bwd_f32(const float* y, const float* p, int64_t n, float* loss, float* dp, float* dz,
+                                   void* stream) {
+  if (!y || !p || n <= 0) return REC_E_ARG;
+  hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(1024), 0, as_stream(stream), y, p, n, loss, dp, dz);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_adam_dense_f32(float* var, float* m, float* v, const float* g, int64_t n, int64_t t, float lr,
+                                  float b1, float b2, float eps, void* stream) {
+  if (!var || !m || !v || !g || n < 0 || t < 1) return REC_E_ARG;
+  if (n == 0) return REC_OK;
+  hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, as_stream(stream), var, m, v,
+                     g, n, adam_lr_t(lr, b1, b2, t), b1, b2, eps);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_adam_sparse_keras_f32(float* var, float* m, float* v, int64_t V, int E, const int64_t* uniq_ids,
+                                         const float* g_rows, const int64_t* n_uniq, int64_t cap, float* side,
+                                         int64_t t, float lr, float b1, float b2, float eps, void* stream) {
+  if (!var || !m || !v || !uniq_ids || !g_rows || !n_uniq || !side || V <= 0 || E <= 0 || cap < 0 || t < 1)
+    return REC_E_ARG;
+  hipStream_t st = as_stream(stream);
+  float lr_t = adam_lr_t(lr, b1, b2, t);
+  if (cap > 0) {
+    hipLaunchKernelGGL(adam_rows_side_kernel, dim3((unsigned)ceil_div64(cap * E, 256)), dim3(256), 0, st, var, m, v, V,
+                       E, uniq_ids, g_rows, n_uniq, cap, side, lr_t, b1, b2, eps);
+    REC_LAUNCH_CHECK();
+  }
+  int64_t n = V * E;
+  if (n % 4 == 0) {
+    int64_t n4 = n / 4;
+    int64_t blocks = ceil_div64(n4, 256);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(adam_sweep_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (float4*)var, (float4*)m,
+                       (float4*)v, n4, lr_t, b1, b2, eps);
+  } else {
+    int64_t blocks = ceil_div64(n, 256);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(adam_sweep_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, st, var, m, v, n, lr_t, b1, b2,
+                       eps);
+  }
+  REC_LAUNCH_CHECK();
+  if (cap > 0) {
+    hipLaunchKernelGGL(adam_rows_patch_kernel, dim3((unsigned)ceil_div64(cap * E, 256)), dim3(256), 0, st, var, m, v, V,
+                       E, uniq_ids, n_uniq, cap, side);
+    REC_LAUNCH_CHECK();
+  }
+  return REC_OK;
+}
+
+extern "C" int rec_adam_rows_f32(float* var, float* m, float* v, int64_t V, int E, const int64_t* uniq_ids,
+                                 const float* g_rows, const int64_t* n_uniq, int64_t cap, int64_t t, float lr, float b1,
+                                 float b2, float eps, void* stream) {
+  if (!var || !m || !v || !uniq_ids || !g_rows || !n_uniq || V <= 0 || E <= 0 || cap < 0 || t < 1) return REC_E_ARG;
+  if (cap == 0) return REC_OK;
+  hipLaunchKernelGGL(adam_rows_lazy_kernel, dim3((unsigned)ceil_div64(cap * E, 256)), dim3(256), 0, as_stream(stream),
+                     var, m, v, V, E, uniq_ids, g_rows, n_uniq, cap, adam_lr_t(lr, b1, b2, t), b1, b2, eps);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}

@@ -1,0 +1,304 @@
+// Embedding lookup + FM interaction kernels (SURVEY.md rows K1-K4 values).
+//   K1  index assembly        2.FM/CustomLayers.py:138-144
+//   K2  Embedding gather      2.FM/CustomLayers.py:129-134,146-147
+//   K3  FM sum-square trick   2.FM/CustomLayers.py:149-155  (fused with K2)
+//   K4  per-lookup gradient values of the FM part (IndexedSlices values), 2.FM/ModelManager.py:176-177
+//
+// HBM-bound gathers: a row of E fp32 is read by LPR = E/4 adjacent lanes as float4 (one 64-B request for
+// E=16), one lane group per example, the F row loads of an example issued back to back so that every
+// lane keeps >= 8 independent 16-B loads in flight; sum / sum-of-squares accumulate in registers and the
+// E-reduction is a wave shuffle butterfly inside the lane group.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// K1
+// ------------------------------------------------------------------------------------------------
+struct ColPtrs {
+  const int64_t* p[REC_MAX_COLS];
+};
+
+__global__ __launch_bounds__(256) void index_pack_kernel(ColPtrs cols, int F, int64_t rows, int64_t* X,
+                                                         int64_t ldx, int64_t col0) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= rows * F) return;
+  int64_t r = t / F;
+  int f = (int)(t - r * F);
+  X[r * ldx + col0 + f] = cols.p[f][r];
+}
+
+extern "C" int rec_index_pack_i64(const int64_t* const* cols_host, int F, int64_t rows, int64_t* X,
+                                  int64_t ldx, int64_t col0, void* stream) {
+  if (!cols_host || !X || F <= 0 || rows < 0 || ldx < col0 + F) return REC_E_ARG;
+  if (rows == 0) return REC_OK;
+  for (int f0 = 0; f0 < F; f0 += REC_MAX_COLS) {
+    int nf = F - f0 < REC_MAX_COLS ? F - f0 : REC_MAX_COLS;
+    ColPtrs cp;
+    for (int f = 0; f < nf; ++f) {
+      if (!cols_host[f0 + f]) return REC_E_ARG;
+      cp.p[f] = cols_host[f0 + f];
+    }
+    int64_t total = rows * nf;
+    hipLaunchKernelGGL(index_pack_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0,
+                       as_stream(stream), cp, nf, rows, X, ldx, col0 + f0);
+    REC_LAUNCH_CHECK();
+  }
+  return REC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2  plain gather
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_vec4_kernel(const float4* __restrict__ table, int64_t V, int lpr,
+                                                          const int64_t* __restrict__ idx, int64_t n,
+                                                          float4* __restrict__ out, int* oob) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * lpr) return;
+  int64_t r = t / lpr;
+  int c = (int)(t - r * lpr);
+  int64_t id = idx[r];
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if ((uint64_t)id < (uint64_t)V) {
+    v = table[id * lpr + c];
+  } else if (oob) {
+    *oob = 1;
+  }
+  out[t] = v;
+}
+
+__global__ __launch_bounds__(256) void gather_scalar_kernel(const float* __restrict__ table, int64_t V, int E,
+                                                            const int64_t* __restrict__ idx, int64_t n,
+                                                            float* __restrict__ out, int* oob) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * E) return;
+  int64_t r = t / E;
+  int d = (int)(t - r * E);
+  int64_t id = idx[r];
+  float v = 0.f;
+  if ((uint64_t)id < (uint64_t)V) {
+    v = table[id * E + d];
+  } else if (oob) {
+    *oob = 1;
+  }
+  out[t] = v;
+}
+
+extern "C" int rec_emb_gather_f32(const float* table, int64_t V, int E, const int64_t* idx, int64_t n,
+                                  float* out, int* oob_flag, void* stream) {
+  if (!table || !idx || !out || V <= 0 || E <= 0 || n < 0) return REC_E_ARG;
+  if (n == 0) return REC_OK;
+  if (E % 4 == 0) {
+    int lpr = E / 4;
+    hipLaunchKernelGGL(gather_vec4_kernel, dim3((unsigned)ceil_div64(n * lpr, 256)), dim3(256), 0,
+                       as_stream(stream), (const float4*)table, V, lpr, idx, n, (float4*)out, oob_flag);
+  } else {
+    hipLaunchKernelGGL(gather_scalar_kernel, dim3((unsigned)ceil_div64(n * E, 256)), dim3(256), 0,
+                       as_stream(stream), table, V, E, idx, n, out, oob_flag);
+  }
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2+K3 fused forward.  Vector form: E = 4*LPR, LPR in {1,2,4,8,16}.
+// ------------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void emb_fm_fwd_vec_kernel(
+    const float4* __restrict__ embed, const float* __restrict__ w, const float* __restrict__ bias, int64_t V,
+    const int64_t* __restrict__ idx, int64_t B, int F, float* __restrict__ z, float* __restrict__ prob,
+    float4* __restrict__ emb_out, float4* __restrict__ sumvec, int* oob) {
+  constexpr int UNR = 8;
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t b = t / LPR;
+  int c = (int)(t % LPR);
+  if (b >= B) return;  // whole lane groups leave together (256 % LPR == 0)
+  const int64_t* ids = idx + b * F;
+  float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 Q = make_float4(0.f, 0.f, 0.f, 0.f);
+  float first = 0.f;
+  bool bad = false;
+  for (int f0 = 0; f0 < F; f0 += UNR) {
+    int64_t id[UNR];
+    float4 e[UNR];
+    float wv[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) id[u] = (f0 + u < F) ? ids[f0 + u] : -1;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      bool ok = (uint64_t)id[u] < (uint64_t)V;
+      bad |= (f0 + u < F) && !ok;
+      e[u] = ok ? embed[id[u] * LPR + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      // the F first-order scalars of an example are spread over the LPR lanes of its group
+      wv[u] = (ok && ((f0 + u) % LPR) == c) ? w[id[u]] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      S.x += e[u].x; S.y += e[u].y; S.z += e[u].z; S.w += e[u].w;
+      Q.x += e[u].x * e[u].x; Q.y += e[u].y * e[u].y; Q.z += e[u].z * e[u].z; Q.w += e[u].w * e[u].w;
+      first += wv[u];
+      if (emb_out && f0 + u < F) emb_out[(b * F + f0 + u) * LPR + c] = e[u];
+    }
+  }
+  if (bad && oob) *oob = 1;
+  float part = (S.x * S.x - Q.x) + (S.y * S.y - Q.y) + (S.z * S.z - Q.z) + (S.w * S.w - Q.w);
+  part = group_sum<LPR>(part);
+  first = group_sum<LPR>(first);
+  if (sumvec) sumvec[b * LPR + c] = S;
+  if (c == 0) {
+    float zz = bias[0] + first + 0.5f * part;
+    if (z) z[b] = zz;
+    if (prob) prob[b] = sigmoid_acc(zz);
+  }
+}
+
+// Generic form: any E <= 4*64; a group of GW lanes (power of two >= min(E,64)) per example, lane c owns
+// dims c, c+GW, ...
+template <int GW, int NACC>
+__global__ __launch_bounds__(256) void emb_fm_fwd_gen_kernel(
+    const float* __restrict__ embed, const float* __restrict__ w, const float* __restrict__ bias, int64_t V,
+    int E, const int64_t* __restrict__ idx, int64_t B, int F, float* __restrict__ z, float* __restrict__ prob,
+    float* __restrict__ emb_out, float* __restrict__ sumvec, int* oob) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t b = t / GW;
+  int c = (int)(t % GW);
+  if (b >= B) return;
+  const int64_t* ids = idx + b * F;
+  float S[NACC], Q[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) S[a] = Q[a] = 0.f;
+  float first = 0.f;
+  bool bad = false;
+  for (int f = 0; f < F; ++f) {
+    int64_t id = ids[f];
+    bool ok = (uint64_t)id < (uint64_t)V;
+    bad |= !ok;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+      int d = c + a * GW;
+      float e = (ok && d < E) ? embed[id * E + d] : 0.f;
+      S[a] += e;
+      Q[a] += e * e;
+      if (emb_out && d < E) emb_out[(b * F + f) * E + d] = e;
+    }
+    if (ok && (f % GW) == c) first += w[id];
+  }
+  if (bad && oob) *oob = 1;
+  float part = 0.f;
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    part += S[a] * S[a] - Q[a];
+    int d = c + a * GW;
+    if (sumvec && d < E) sumvec[b * E + d] = S[a];
+  }
+  part = group_sum<GW>(part);
+  first = group_sum<GW>(first);
+  if (c == 0) {
+    float zz = bias[0] + first + 0.5f * part;
+    if (z) z[b] = zz;
+    if (prob) prob[b] = sigmoid_acc(zz);
+  }
+}
+
+#define FWD_VEC(LPR)                                                                                     \
+  hipLaunchKernelGGL(emb_fm_fwd_vec_kernel<LPR>, dim3((unsigned)ceil_div64(B * LPR, 256)), dim3(256), 0, \
+                     as_stream(stream), (const float4*)embed, w, bias, V, idx, B, F, z, prob,             \
+                     (float4*)emb_out, (float4*)sumvec, oob_flag)
+#define FWD_GEN(GW, NACC)                                                                                      \
+  hipLaunchKernelGGL((emb_fm_fwd_gen_kernel<GW, NACC>), dim3((unsigned)ceil_div64(B * GW, 256)), dim3(256), 0, \
+                     as_stream(stream), embed, w, bias, V, E, idx, B, F, z, prob, emb_out, sumvec, oob_flag)
+
+extern "C" int rec_emb_fm_fwd_f32(const float* embed, const float* w, const float* bias, int64_t V, int E,
+                                  const int64_t* idx, int64_t B, int F, float* z, float* prob, float* emb_out,
+                                  float* sumvec, int* oob_flag, void* stream) {
+  if (!embed || !w || !bias || !idx || V <= 0 || E <= 0 || B < 0 || F <= 0) return REC_E_ARG;
+  if (E > 256) return REC_E_UNSUPPORTED;
+  if (B == 0) return REC_OK;
+  switch (E) {
+    case 4: FWD_VEC(1); break;
+    case 8: FWD_VEC(2); break;
+    case 16: FWD_VEC(4); break;
+    case 32: FWD_VEC(8); break;
+    case 64: FWD_VEC(16); break;
+    default:
+      if (E <= 1) FWD_GEN(1, 1);
+      else if (E <= 2) FWD_GEN(2, 1);
+      else if (E <= 4) FWD_GEN(4, 1);
+      else if (E <= 8) FWD_GEN(8, 1);
+      else if (E <= 16) FWD_GEN(16, 1);
+      else if (E <= 32) FWD_GEN(32, 1);
+      else if (E <= 64) FWD_GEN(64, 1);
+      else if (E <= 128) FWD_GEN(64, 2);
+      else FWD_GEN(64, 4);
+  }
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4 values
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void emb_fm_bwd_vals_kernel(
+    const float* __restrict__ embed, int64_t V, int E, const int64_t* __restrict__ idx, int64_t B, int F,
+    const float* __restrict__ gz, const float* __restrict__ sumvec, const float* __restrict__ emb_rows,
+    const float* __restrict__ extra, float* __restrict__ dvals) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t total = B * F * E;
+  if (t >= total) return;
+  int64_t j = t / E;  // lookup
+  int d = (int)(t - j * E);
+  int64_t b = j / F;
+  float e;
+  if (emb_rows) {
+    e = emb_rows[t];
+  } else {
+    int64_t id = idx[j];
+    e = ((uint64_t)id < (uint64_t)V) ? embed[id * E + d] : 0.f;
+  }
+  float v = gz[b] * (sumvec[b * E + d] - e);
+  if (extra) v += extra[t];
+  dvals[t] = v;
+}
+
+__global__ __launch_bounds__(256) void emb_fm_bwd_vals_vec_kernel(
+    const float4* __restrict__ embed, int64_t V, int lpr, const int64_t* __restrict__ idx, int64_t B, int F,
+    const float* __restrict__ gz, const float4* __restrict__ sumvec, const float4* __restrict__ emb_rows,
+    const float4* __restrict__ extra, float4* __restrict__ dvals) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t total = B * F * lpr;
+  if (t >= total) return;
+  int64_t j = t / lpr;
+  int c = (int)(t - j * lpr);
+  int64_t b = j / F;
+  float4 e;
+  if (emb_rows) {
+    e = emb_rows[t];
+  } else {
+    int64_t id = idx[j];
+    e = ((uint64_t)id < (uint64_t)V) ? embed[id * lpr + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float g = gz[b];
+  float4 s = sumvec[b * lpr + c];
+  float4 v = make_float4(g * (s.x - e.x), g * (s.y - e.y), g * (s.z - e.z), g * (s.w - e.w));
+  if (extra) {
+    float4 x = extra[t];
+    v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+  }
+  dvals[t] = v;
+}
+
+extern "C" int rec_emb_fm_bwd_vals_f32(const float* embed, int64_t V, int E, const int64_t* idx, int64_t B,
+                                       int F, const float* gz, const float* sumvec, const float* emb_rows,
+                                       const float* extra, float* dvals, void* stream) {
+  if ((!embed && !emb_rows) || !idx || !gz || !sumvec || !dvals || E <= 0 || F <= 0 || B < 0) return REC_E_ARG;
+  if (B == 0) return REC_OK;
+  if (E % 4 == 0) {
+    int lpr = E / 4;
+    hipLaunchKernelGGL(emb_fm_bwd_vals_vec_kernel, dim3((unsigned)ceil_div64(B * F * lpr, 256)), dim3(256), 0,
+                       as_stream(stream), (const float4*)embed, V, lpr, idx, B, F, gz, (const float4*)sumvec,
+                       (const float4*)emb_rows, (const float4*)extra, (float4*)dvals);
+  } else {
+    hipLaunchKernelGGL(emb_fm_bwd_vals_kernel, dim3((unsigned)ceil_div64(B * F * E, 256)), dim3(256), 0,
+                       as_stream(stream), embed, V, E, idx, B, F, gz, sumvec, emb_rows, extra, dvals);
+  }
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}

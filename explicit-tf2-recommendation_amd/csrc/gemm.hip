@@ -1,0 +1,149 @@
+// fp32-exact dense GEMM on the gfx950 matrix cores: C[M,N] = epi(op(A).op(B)).
+// Serves MLPLayer MatMul+BiasAdd+activation (2.FM/CustomLayers.py:74-81), Keras Dense
+// (3.DCN/CustomLayers.py:158-167), MatrixCrossLayer x0*(W x_l + b) + x_l (3.DCN/CustomLayers.py:301-303)
+// and the three backward GEMMs of each (dX = dY.K^T, dK = X^T.dY with split-K over the batch).
+//
+// v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bit-for-bit a k-ordered fmaf chain (no xf32/TF32
+// shortcut exists on gfx950) -- what the 1e-5 parity through three multiplicative CrossNet layers needs.
+// Tile 64x64x16, 4 waves as 2x2, one 32x32 accumulator (16 VGPRs) per wave.  LDS tiles are k-major
+// ([k][m], [k][n]) so that an MFMA operand fetch is one conflict-free ds_read_b32 per lane.
+// Loads are scalar and guarded, so any M, N, K and any leading dimension work (D = 323, 835 are odd).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 16, PAD = 1;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float epilogue(int epi, float acc, int64_t gm, int64_t gn, const float* bias,
+                                          const float* e0, int64_t lde0, const float* e1, int64_t lde1) {
+  switch (epi) {
+    case REC_EPI_BIAS: return acc + bias[gn];
+    case REC_EPI_BIAS_RELU: return fmaxf(acc + bias[gn], 0.f);
+    case REC_EPI_BIAS_SIGMOID: return sigmoid_acc(acc + bias[gn]);
+    case REC_EPI_BIAS_TANH: return tanhf(acc + bias[gn]);
+    case REC_EPI_CROSS: return e0[gm * lde0 + gn] * (acc + bias[gn]) + e1[gm * lde1 + gn];
+    case REC_EPI_ADD: return acc + e1[gm * lde1 + gn];
+    default: return acc;
+  }
+}
+
+template <int TA, int TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A,
+                                                       int64_t lda, const float* __restrict__ B, int64_t ldb,
+                                                       float* __restrict__ C, int64_t ldc, int epi,
+                                                       const float* __restrict__ bias, const float* __restrict__ e0,
+                                                       int64_t lde0, const float* __restrict__ e1, int64_t lde1,
+                                                       int64_t kchunk, float* __restrict__ ws) {
+  __shared__ float As[BK][BM + PAD];
+  __shared__ float Bs[BK][BN + PAD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.x * BM, n0 = (int64_t)blockIdx.y * BN;
+  const int64_t k_begin = (int64_t)blockIdx.z * kchunk;
+  const int64_t k_end = (k_begin + kchunk < K) ? k_begin + kchunk : K;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
+#pragma unroll
+    for (int i = 0; i < (BM * BK) / 256; ++i) {
+      int e = tid + i * 256;
+      int m, k;
+      if (TA == 0) { m = e / BK; k = e % BK; } else { k = e / BM; m = e % BM; }
+      int64_t gm = m0 + m, gk = k0 + k;
+      float v = 0.f;
+      if (gm < M && gk < k_end) v = (TA == 0) ? A[gm * lda + gk] : A[gk * lda + gm];
+      As[k][m] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < (BN * BK) / 256; ++i) {
+      int e = tid + i * 256;
+      int n, k;
+      if (TB == 0) { k = e / BN; n = e % BN; } else { n = e / BK; k = e % BK; }
+      int64_t gn = n0 + n, gk = k0 + k;
+      float v = 0.f;
+      if (gn < N && gk < k_end) v = (TB == 0) ? B[gk * ldb + gn] : B[gn * ldb + gk];
+      Bs[k][n] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
+      float b = Bs[kk + (lane >> 5)][wn * 32 + (lane & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  const int col = lane & 31;
+  const int64_t gn = n0 + wn * 32 + col;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    int64_t gm = m0 + wm * 32 + row;
+    if (gm < M && gn < N) {
+      if (ws) {
+        ws[((int64_t)blockIdx.z * M + gm) * N + gn] = acc[r];
+      } else {
+        C[gm * ldc + gn] = epilogue(epi, acc[r], gm, gn, bias, e0, lde0, e1, lde1);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int split, int64_t M,
+                                                            int64_t N, float* __restrict__ C, int64_t ldc, int epi,
+                                                            const float* __restrict__ bias, const float* __restrict__ e0,
+                                                            int64_t lde0, const float* __restrict__ e1, int64_t lde1) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= M * N) return;
+  int64_t gm = t / N, gn = t - gm * N;
+  float acc = 0.f;
+  for (int z = 0; z < split; ++z) acc += ws[(int64_t)z * M * N + t];  // fixed order
+  C[gm * ldc + gn] = epilogue(epi, acc, gm, gn, bias, e0, lde0, e1, lde1);
+}
+
+}  // namespace
+
+extern "C" int rec_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                            const float* B, int64_t ldb, float* C, int64_t ldc, int epilogue_kind,
+                            const float* bias, const float* e0, int64_t lde0, const float* e1, int64_t lde1,
+                            int split_k, float* workspace, void* stream) {
+  if (!A || !B || !C || M < 0 || N < 0 || K < 0) return REC_E_ARG;
+  if (epilogue_kind < REC_EPI_NONE || epilogue_kind > REC_EPI_ADD) return REC_E_ARG;
+  if (epilogue_kind >= REC_EPI_BIAS && epilogue_kind <= REC_EPI_CROSS && !bias) return REC_E_ARG;
+  if (epilogue_kind == REC_EPI_CROSS && (!e0 || !e1)) return REC_E_ARG;
+  if (epilogue_kind == REC_EPI_ADD && !e1) return REC_E_ARG;
+  if (lda < (transA ? M : K) || ldb < (transB ? K : N) || ldc < N) return REC_E_ARG;
+  if (M == 0 || N == 0) return REC_OK;
+  if (split_k < 1) split_k = 1;
+  if (split_k > 1 && !workspace) return REC_E_WORKSPACE;
+  int64_t kchunk = K;
+  if (split_k > 1) {
+    kchunk = ((ceil_div64(K, split_k) + BK - 1) / BK) * BK;
+    if (kchunk < BK) kchunk = BK;
+    split_k = (int)ceil_div64(K, kchunk);
+    if (split_k < 1) split_k = 1;
+  }
+  float* ws = split_k > 1 ? workspace : nullptr;
+  dim3 grid((unsigned)ceil_div64(M, BM), (unsigned)ceil_div64(N, BN), (unsigned)split_k);
+  if (grid.y > 65535u) return REC_E_UNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+#define LAUNCH(TA, TB)                                                                                        \
+  hipLaunchKernelGGL((gemm_f32_kernel<TA, TB>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc,      \
+                     epilogue_kind, bias, e0, lde0, e1, lde1, kchunk, ws)
+  if (!transA && !transB) LAUNCH(0, 0);
+  else if (!transA && transB) LAUNCH(0, 1);
+  else if (transA && !transB) LAUNCH(1, 0);
+  else LAUNCH(1, 1);
+#undef LAUNCH
+  REC_LAUNCH_CHECK();
+  if (ws) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div64(M * N, 256)), dim3(256), 0, st, ws, split_k,
+                       M, N, C, ldc, epilogue_kind, bias, e0, lde0, e1, lde1);
+    REC_LAUNCH_CHECK();
+  }
+  return REC_OK;
+}

@@ -1,0 +1,292 @@
+"""Tensor-level wrappers over the C ABI (include/mi355rec.h).
+
+torch is plumbing here: it owns device memory and the current HIP stream; every function below hands raw
+device pointers and the stream handle to libmi355rec.so and returns torch tensors that view the results.
+Nothing in this file computes on the CPU or through torch ops -- a non-CUDA tensor is an error.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import lib, check
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_SIGMOID, EPI_BIAS_TANH, EPI_CROSS, EPI_ADD = range(7)
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = range(4)
+ACT_CODE = {None: ACT_NONE, "linear": ACT_NONE, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID, "tanh": ACT_TANH}
+EPI_OF_ACT = {ACT_NONE: EPI_BIAS, ACT_RELU: EPI_BIAS_RELU, ACT_SIGMOID: EPI_BIAS_SIGMOID, ACT_TANH: EPI_BIAS_TANH}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _req(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("%s must be a tensor on the MI355X (got %r): the HIP path has no CPU fallback"
+                           % (name, getattr(t, "device", type(t))))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t
+
+
+def _f32(t, name):
+    return _req(t, torch.float32, name)
+
+
+def _i64(t, name):
+    return _req(t, torch.int64, name)
+
+
+# ---------------------------------------------------------------------------------------------------
+# K1 / K2 / K3
+# ---------------------------------------------------------------------------------------------------
+
+def index_pack(cols, out=None, col0=0):
+    """cols: list of int64 tensors with the same number of elements ([B], [B,1] or [B,T]).
+    Returns X [rows, F] int64 (expand_dims + concat(axis=1), 2.FM/CustomLayers.py:138-144)."""
+    F = len(cols)
+    rows = cols[0].numel()
+    for c in cols:
+        _i64(c, "index column")
+        if c.numel() != rows:
+            raise ValueError("index columns differ in length")
+    if out is None:
+        out = torch.empty((rows, F), dtype=torch.int64, device=cols[0].device)
+    arr = (C.c_void_p * F)(*[c.data_ptr() for c in cols])
+    check(lib.rec_index_pack_i64(arr, F, rows, _ptr(out), out.shape[1], col0, _stream()), "rec_index_pack_i64")
+    return out
+
+
+def new_flag(device):
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def emb_gather(table, idx, oob=None):
+    _f32(table, "table"); _i64(idx, "idx")
+    V, E = table.shape
+    out = torch.empty(tuple(idx.shape) + (E,), dtype=torch.float32, device=table.device)
+    check(lib.rec_emb_gather_f32(_ptr(table), V, E, _ptr(idx), idx.numel(), _ptr(out), _ptr(oob), _stream()),
+          "rec_emb_gather_f32")
+    return out
+
+
+def emb_fm_fwd(embed, w, bias, X, want_prob=False, want_rows=False, want_sum=True, oob=None):
+    """Fused w(X), embed(X) and the FM sum-square trick.  Returns z [B], prob [B]|None, rows [B,F,E]|None,
+    sumvec [B,E]|None."""
+    _f32(embed, "embed"); _f32(w, "w"); _f32(bias, "bias"); _i64(X, "X")
+    V, E = embed.shape
+    B, F = X.shape
+    dev = embed.device
+    z = torch.empty(B, dtype=torch.float32, device=dev)
+    prob = torch.empty(B, dtype=torch.float32, device=dev) if want_prob else None
+    rows = torch.empty((B, F, E), dtype=torch.float32, device=dev) if want_rows else None
+    S = torch.empty((B, E), dtype=torch.float32, device=dev) if want_sum else None
+    check(lib.rec_emb_fm_fwd_f32(_ptr(embed), _ptr(w), _ptr(bias), V, E, _ptr(X), B, F, _ptr(z), _ptr(prob),
+                                 _ptr(rows), _ptr(S), _ptr(oob), _stream()), "rec_emb_fm_fwd_f32")
+    return z, prob, rows, S
+
+
+def emb_fm_bwd_vals(embed, X, gz, sumvec, rows=None, extra=None):
+    """IndexedSlices values of the FM part: [B*F, E]."""
+    V, E = embed.shape
+    B, F = X.shape
+    out = torch.empty((B * F, E), dtype=torch.float32, device=embed.device)
+    check(lib.rec_emb_fm_bwd_vals_f32(_ptr(embed), V, E, _ptr(X), B, F, _ptr(_f32(gz, "gz")), _ptr(sumvec),
+                                      _ptr(rows), _ptr(extra), _ptr(out), _stream()), "rec_emb_fm_bwd_vals_f32")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# K4 de-duplication
+# ---------------------------------------------------------------------------------------------------
+
+class DedupPlan:
+    """Sorted-unique plan of a flat id list; reusable for every table indexed by the same ids."""
+
+    def __init__(self, ids, V):
+        ids = _i64(ids.reshape(-1), "ids")
+        n = ids.numel()
+        dev = ids.device
+        self.n = n
+        self.uniq_ids = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+        self.seg_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        self.perm = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        self.n_uniq = torch.empty(1, dtype=torch.int64, device=dev)
+        nbytes = lib.rec_dedup_workspace_bytes(n)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        check(lib.rec_dedup_plan_i64(_ptr(ids), n, V, _ptr(self.uniq_ids), _ptr(self.seg_start), _ptr(self.perm),
+                                     _ptr(self.n_uniq), _ptr(ws), nbytes, _stream()), "rec_dedup_plan_i64")
+
+    def segment_sum(self, vals, E, row_div=1):
+        """vals [n/row_div, E] -> [n, E]; rows >= n_uniq are zero."""
+        out = torch.empty((max(self.n, 1), E), dtype=torch.float32, device=vals.device)
+        check(lib.rec_segment_sum_f32(_ptr(_f32(vals, "vals")), E, _ptr(self.perm), _ptr(self.seg_start), self.n,
+                                      row_div, _ptr(out), _stream()), "rec_segment_sum_f32")
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# dense
+# ---------------------------------------------------------------------------------------------------
+
+def gemm(A, B, transA=False, transB=False, epi=EPI_NONE, bias=None, e0=None, e1=None, split_k=1, out=None):
+    """C = epi(op(A) @ op(B)) on the fp32 matrix cores.  A, B are 2-D row-major (leading dim = stride(0))."""
+    for t, nm in ((A, "A"), (B, "B")):
+        if t.dtype != torch.float32 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
+            raise ValueError("%s must be a 2-D fp32 CUDA tensor with unit inner stride" % nm)
+    M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
+    K2, N = (B.shape[1], B.shape[0]) if transB else (B.shape[0], B.shape[1])
+    if K != K2:
+        raise ValueError("gemm inner dimensions differ: %d vs %d" % (K, K2))
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    ws = None
+    if split_k > 1:
+        ws = torch.empty((split_k, M, N), dtype=torch.float32, device=A.device)
+    check(lib.rec_gemm_f32(int(transA), int(transB), M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out),
+                           out.stride(0), epi, _ptr(bias), _ptr(e0), e0.stride(0) if e0 is not None else 0,
+                           _ptr(e1), e1.stride(0) if e1 is not None else 0, split_k, _ptr(ws), _stream()),
+          "rec_gemm_f32")
+    return out
+
+
+def act_bwd(act, post, dpost):
+    out = torch.empty_like(dpost)
+    check(lib.rec_act_bwd_f32(act, _ptr(_f32(post, "post")), _ptr(_f32(dpost, "dpost")), _ptr(out), post.numel(),
+                              _stream()), "rec_act_bwd_f32")
+    return out
+
+
+def colsum(X):
+    M, N = X.shape
+    out = torch.empty(N, dtype=torch.float32, device=X.device)
+    check(lib.rec_colsum_f32(_ptr(X), M, N, X.stride(0), _ptr(out), _stream()), "rec_colsum_f32")
+    return out
+
+
+def axpby(a, x, b, y):
+    check(lib.rec_axpby_f32(a, _ptr(_f32(x, "x")), b, _ptr(_f32(y, "y")), x.numel(), _stream()), "rec_axpby_f32")
+    return y
+
+
+def copy_cols(src, dst_view):
+    """dst_view[:, :] = src, both 2-D with unit inner stride (dst may be a column block of a wider buffer)."""
+    rows, w = src.shape
+    check(lib.rec_copy_cols_f32(_ptr(src), src.stride(0), _ptr(dst_view), dst_view.stride(0), rows, w, _stream()),
+          "rec_copy_cols_f32")
+    return dst_view
+
+
+def split_k_for(K, M, N):
+    """Heuristic split of a reduction over the batch so that ~>=256 workgroups run."""
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    if tiles >= 256 or K < 1024:
+        return 1
+    return int(max(1, min(64, 512 // max(tiles, 1), K // 256)))
+
+
+# ---------------------------------------------------------------------------------------------------
+# CrossNet vector mode, cosine, BCE, Adam
+# ---------------------------------------------------------------------------------------------------
+
+def crossnet_vec_fwd(x0, w, b, save=True):
+    B, D = x0.shape
+    L = w.shape[0]
+    y = torch.empty_like(x0)
+    xs = torch.empty((L, B, D), dtype=torch.float32, device=x0.device) if save else None
+    check(lib.rec_crossnet_vec_fwd_f32(_ptr(_f32(x0, "x0")), B, D, L, _ptr(_f32(w, "w")), _ptr(_f32(b, "b")),
+                                       _ptr(y), _ptr(xs), _stream()), "rec_crossnet_vec_fwd_f32")
+    return y, xs
+
+
+def crossnet_vec_bwd(x0, w, xs, gy):
+    B, D = x0.shape
+    L = w.shape[0]
+    gx0 = torch.empty_like(x0)
+    dw = torch.empty_like(w)
+    db = torch.empty_like(w)
+    nbytes = lib.rec_crossnet_vec_bwd_workspace_bytes(B, D, L)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x0.device)
+    check(lib.rec_crossnet_vec_bwd_f32(_ptr(x0), B, D, L, _ptr(w), _ptr(xs), _ptr(_f32(gy, "gy")), _ptr(gx0),
+                                       _ptr(dw), _ptr(db), _ptr(ws), _stream()), "rec_crossnet_vec_bwd_f32")
+    return gx0, dw, db
+
+
+def cosine_fwd(u, i):
+    B, d = u.shape
+    out = torch.empty(B, dtype=torch.float32, device=u.device)
+    check(lib.rec_cosine_fwd_f32(_ptr(_f32(u, "u")), _ptr(_f32(i, "i")), B, d, _ptr(out), _stream()),
+          "rec_cosine_fwd_f32")
+    return out
+
+
+def cosine_bwd(u, i, gout):
+    B, d = u.shape
+    gu, gi = torch.empty_like(u), torch.empty_like(i)
+    check(lib.rec_cosine_bwd_f32(_ptr(u), _ptr(i), B, d, _ptr(_f32(gout, "gout")), _ptr(gu), _ptr(gi), _stream()),
+          "rec_cosine_bwd_f32")
+    return gu, gi
+
+
+def bce_fwd_bwd(y, p, want_dp=True, want_dz=False):
+    y = _f32(y.reshape(-1), "y")
+    p = _f32(p.reshape(-1), "p")
+    n = p.numel()
+    loss = torch.empty(1, dtype=torch.float32, device=p.device)
+    dp = torch.empty(n, dtype=torch.float32, device=p.device) if want_dp else None
+    dz = torch.empty(n, dtype=torch.float32, device=p.device) if want_dz else None
+    check(lib.rec_bce_fwd_bwd_f32(_ptr(y), _ptr(p), n, _ptr(loss), _ptr(dp), _ptr(dz), _stream()),
+          "rec_bce_fwd_bwd_f32")
+    return loss, dp, dz
+
+
+def adam_dense(var, m, v, g, t, lr, b1=0.9, b2=0.999, eps=1e-7):
+    check(lib.rec_adam_dense_f32(_ptr(_f32(var, "var")), _ptr(m), _ptr(v), _ptr(_f32(g, "g")), var.numel(), t, lr,
+                                 b1, b2, eps, _stream()), "rec_adam_dense_f32")
+
+
+def adam_sparse_keras(var, m, v, uniq_ids, g_rows, n_uniq, t, lr, b1=0.9, b2=0.999, eps=1e-7):
+    V, E = var.shape
+    cap = g_rows.shape[0]
+    side = torch.empty((cap, 3, E), dtype=torch.float32, device=var.device)
+    check(lib.rec_adam_sparse_keras_f32(_ptr(var), _ptr(m), _ptr(v), V, E, _ptr(uniq_ids), _ptr(g_rows), _ptr(n_uniq),
+                                        cap, _ptr(side), t, lr, b1, b2, eps, _stream()), "rec_adam_sparse_keras_f32")
+
+
+def adam_rows(var, m, v, uniq_ids, g_rows, n_uniq, t, lr, b1=0.9, b2=0.999, eps=1e-7):
+    V, E = var.shape
+    check(lib.rec_adam_rows_f32(_ptr(var), _ptr(m), _ptr(v), V, E, _ptr(uniq_ids), _ptr(g_rows), _ptr(n_uniq),
+                                g_rows.shape[0], t, lr, b1, b2, eps, _stream()), "rec_adam_rows_f32")
+
+
+# ---------------------------------------------------------------------------------------------------
+# sharding
+# ---------------------------------------------------------------------------------------------------
+
+def shard_bucketize(ids, rows_per_shard, n_shard, oob=None):
+    ids = _i64(ids.reshape(-1), "ids")
+    n = ids.numel()
+    dev = ids.device
+    perm = torch.empty(n, dtype=torch.int64, device=dev)
+    counts = torch.empty(n_shard, dtype=torch.int64, device=dev)
+    local = torch.empty(n, dtype=torch.int64, device=dev)
+    nbytes = lib.rec_shard_bucketize_workspace_bytes(n, n_shard)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    check(lib.rec_shard_bucketize_i64(_ptr(ids), n, rows_per_shard, n_shard, _ptr(perm), _ptr(counts), _ptr(local),
+                                      _ptr(oob), _ptr(ws), nbytes, _stream()), "rec_shard_bucketize_i64")
+    return perm, counts, local
+
+
+def permute_rows(x, perm, scatter):
+    """scatter=True: out[perm[i]] = x[i];  scatter=False: out[i] = x[perm[i]]."""
+    n, E = x.shape
+    out = torch.empty_like(x)
+    check(lib.rec_permute_rows_f32(_ptr(_f32(x, "x")), _ptr(_i64(perm, "perm")), n, E, int(scatter), _ptr(out),
+                                   _stream()), "rec_permute_rows_f32")
+    return out

@@ -1,0 +1,169 @@
+/* mi355rec.h -- C ABI of libmi355rec.so: the MI355X (gfx950) embedding + feature-interaction engine.
+ *
+ * Drop-in boundary.  The reference (PatrickHwang/Explicit-tf2-Recommendation) is pure Python/TF2 and has
+ * no FFI of its own; its boundary for this path is the Keras `Layer.__call__` protocol of
+ * 2.FM/CustomLayers.py, 3.DCN/CustomLayers.py, 5.DIN/CustomLayers.py as driven by
+ * 2.FM/ModelManager.py:87-96,171-181.  Each entry point below replaces the TF op sequence cited next to
+ * it; the Python mirror of the Layer classes
+ * (explicit-tf2-recommendation_amd/layers.py) is the only caller and binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in `_host`;
+ *   - all matrices are dense row-major fp32, index tensors are int64 (as the reference's Inputs are,
+ *     2.FM/ModelManager.py:92);
+ *   - `stream` is a hipStream_t passed as void*; every call only ENQUEUES work on it (no allocation, no
+ *     synchronisation, graph-capture safe); inputs are borrowed for the duration of the enqueued work;
+ *   - return value: 0 ok, <0 argument error (REC_E_*), >0 a hipError_t from the launch;
+ *   - `oob_flag` (optional int32*): kernels never read outside a table -- an id outside [0,V) contributes
+ *     a zero row and sets *oob_flag = 1, which the Python layer turns into IndexError (the reference
+ *     raises InvalidArgumentError on CPU, aliased wrapError at 2.FM/CustomLayers.py:8).
+ */
+#ifndef MI355REC_H
+#define MI355REC_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REC_OK 0
+#define REC_E_ARG (-1)
+#define REC_E_UNSUPPORTED (-2)
+#define REC_E_WORKSPACE (-3)
+
+#define REC_MAX_COLS 64
+
+/* activation kinds shared by the dense entry points */
+enum { REC_ACT_NONE = 0, REC_ACT_RELU = 1, REC_ACT_SIGMOID = 2, REC_ACT_TANH = 3 };
+
+/* epilogues of rec_gemm_f32 */
+enum {
+  REC_EPI_NONE = 0,      /* C = A.B                                   */
+  REC_EPI_BIAS = 1,      /* C = A.B + bias[n]                          */
+  REC_EPI_BIAS_RELU = 2, /* C = relu(A.B + bias[n])                    */
+  REC_EPI_BIAS_SIGMOID = 3,
+  REC_EPI_BIAS_TANH = 4,
+  REC_EPI_CROSS = 5,     /* C = e0[m,n] * (A.B + bias[n]) + e1[m,n]    (MatrixCrossLayer, 3.DCN/CustomLayers.py:301-303) */
+  REC_EPI_ADD = 6        /* C = A.B + e1[m,n]                          */
+};
+
+int rec_version(void);
+
+/* ---- K1  index assembly: expand_dims + concat(axis=1) of F int64 columns (2.FM/CustomLayers.py:138-144).
+ * cols_host: HOST array of F device pointers, each a column of `rows` int64 (a [B,1] or [B] tensor; for the
+ * DIN series stack, 5.DIN/CustomLayers.py:258, a [B,T] tensor with rows = B*T).  Writes X[r*ldx + col0 + f]. */
+int rec_index_pack_i64(const int64_t* const* cols_host, int F, int64_t rows, int64_t* X, int64_t ldx,
+                       int64_t col0, void* stream);
+
+/* ---- K2  Embedding(V,E)(X) -> gather (2.FM/CustomLayers.py:129-134,146-147).  out[i,:] = table[idx[i],:]. */
+int rec_emb_gather_f32(const float* table, int64_t V, int E, const int64_t* idx, int64_t n, float* out,
+                       int* oob_flag, void* stream);
+
+/* ---- K2+K3 fused: w(X), embed(X), reduce_sum / square / subtract / 0.5*reduce_sum
+ * (2.FM/CustomLayers.py:146-153, 289-297).  z[b] = bias + sum_f w[X[b,f]] + 0.5*sum_d(S_d^2 - sum_f e_fd^2).
+ * Optional outputs (NULL to skip): prob[b] = sigmoid(z[b]) (FMRankingLayer, :155); emb_out [B,F,E] (the
+ * Flatten() input of DeepFM's DNN part, :300); sumvec [B,E] = S (saved for backward). */
+int rec_emb_fm_fwd_f32(const float* embed, const float* w, const float* bias, int64_t V, int E,
+                       const int64_t* idx, int64_t B, int F, float* z, float* prob, float* emb_out,
+                       float* sumvec, int* oob_flag, void* stream);
+
+/* ---- K4 (values): GradientTape gradient of the FM part w.r.t. the gathered rows, as the IndexedSlices
+ * values TF produces (2.FM/ModelManager.py:176-177): dvals[b,f,:] = gz[b]*(S[b,:] - e[b,f,:]) + extra[b,f,:].
+ * emb_rows (optional): the rows saved by the forward; NULL -> re-gather from `embed`.  extra (optional):
+ * gradient arriving through the DNN part. */
+int rec_emb_fm_bwd_vals_f32(const float* embed, int64_t V, int E, const int64_t* idx, int64_t B, int F,
+                            const float* gz, const float* sumvec, const float* emb_rows, const float* extra,
+                            float* dvals, void* stream);
+
+/* ---- K4 (de-duplication): what Keras' optimizer does to an IndexedSlices gradient before applying it
+ * (tf.unique + unsorted_segment_sum); here ids come out ASCENDING and rows of one id are added in a fixed
+ * order, so results are run-to-run bit-identical.
+ * plan: ids[n] -> uniq_ids[n] (first *n_uniq valid, ascending; the tail is padded with uniq_ids[0]),
+ *       seg_start[n+1] (row range of each unique id in the sorted order; empty for the tail),
+ *       perm[n] (sorted position -> original position), n_uniq (device int64). */
+size_t rec_dedup_workspace_bytes(int64_t n);
+int rec_dedup_plan_i64(const int64_t* ids, int64_t n, int64_t V, int64_t* uniq_ids, int32_t* seg_start,
+                       int32_t* perm, int64_t* n_uniq, void* workspace, size_t workspace_bytes,
+                       void* stream);
+/* out[u,:] = sum over s in [seg_start[u], seg_start[u+1]) of vals[perm[s] / row_div, :]   for u in [0,n).
+ * row_div = 1 for per-lookup values; row_div = F broadcasts a per-example value (the w table, whose
+ * per-lookup gradient is gz[b]). */
+int rec_segment_sum_f32(const float* vals, int E, const int32_t* perm, const int32_t* seg_start, int64_t n,
+                        int32_t row_div, float* out, void* stream);
+
+/* ---- K5/K6  dense: C[M,N] = epi(op(A).op(B)), fp32-exact MFMA (v_mfma_f32_32x32x2_f32).
+ * op(A) is [M,K]: transA=0 -> A stored [M,K] (lda), transA=1 -> A stored [K,M].  op(B) is [K,N]:
+ * transB=0 -> B stored [K,N], transB=1 -> B stored [N,K].  MatMul+BiasAdd+activation of MLPLayer
+ * (2.FM/CustomLayers.py:74-81), Keras Dense (3.DCN/CustomLayers.py:158-167), MatrixCrossLayer
+ * (3.DCN/CustomLayers.py:301-303, REC_EPI_CROSS with e0=x0, e1=x_l) and their backward GEMMs.
+ * split_k > 1 needs workspace of split_k*M*N floats (partials are summed in a fixed order). */
+int rec_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                 const float* B, int64_t ldb, float* C, int64_t ldc, int epilogue, const float* bias,
+                 const float* e0, int64_t lde0, const float* e1, int64_t lde1, int split_k,
+                 float* workspace, void* stream);
+
+/* elementwise helpers of the dense backward */
+/* dpre = dpost * act'(post)   (in place allowed) */
+int rec_act_bwd_f32(int act, const float* post, const float* dpost, float* dpre, int64_t n, void* stream);
+/* out[j] = sum_i X[i,j]  (bias gradients), deterministic */
+int rec_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx, float* out, void* stream);
+/* y = a*x + b*y over n elements */
+int rec_axpby_f32(float a, const float* x, float b, float* y, int64_t n, void* stream);
+/* dst[r, c0:c0+w] = src[r, 0:w]   (concat / split along the feature axis) */
+int rec_copy_cols_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int64_t w,
+                      void* stream);
+
+/* ---- K7  CrossLayer, vector mode (3.DCN/CustomLayers.py:195-203): x_{l+1} = x0*(x_l.w_l) + b_l + x_l.
+ * w, b: [L,D].  xs (optional) saves x_0..x_{L-1} as [L,B,D] for backward.  y [B,D]. */
+int rec_crossnet_vec_fwd_f32(const float* x0, int64_t B, int D, int L, const float* w, const float* b,
+                             float* y, float* xs, void* stream);
+/* gx0 [B,D], dw [L,D], db [L,D]; workspace: rec_crossnet_vec_bwd_workspace_bytes(B,D,L). */
+size_t rec_crossnet_vec_bwd_workspace_bytes(int64_t B, int D, int L);
+int rec_crossnet_vec_bwd_f32(const float* x0, int64_t B, int D, int L, const float* w, const float* xs,
+                             const float* gy, float* gx0, float* dw, float* db, void* workspace,
+                             void* stream);
+
+/* ---- K10  two-tower score (2.FM/CustomLayers.py:233-234): out[b] = (1 - cos(u_b, i_b))/2,
+ * l2norm = x*rsqrt(max(sum x^2, 1e-12)). */
+int rec_cosine_fwd_f32(const float* u, const float* i, int64_t B, int d, float* out, void* stream);
+int rec_cosine_bwd_f32(const float* u, const float* i, int64_t B, int d, const float* gout, float* gu,
+                       float* gi, void* stream);
+
+/* ---- K11  reduce_sum(BinaryCrossentropy()(y, p)) and its gradient (2.FM/ModelManager.py:100,175).
+ * p: probabilities [n]; y: labels [n].  loss (device scalar) = mean of -(y log(clip(p)+eps) +
+ * (1-y) log(1-clip(p)+eps)), eps = 1e-7.  dp (optional) = dL/dp; dz (optional) = dL/dp * p(1-p) (sigmoid head). */
+int rec_bce_fwd_bwd_f32(const float* y, const float* p, int64_t n, float* loss, float* dp, float* dz,
+                        void* stream);
+
+/* ---- K12  Keras Adam (2.FM/ModelManager.py:104,178-179).  t = 1-based step.
+ * dense: m += (g-m)(1-b1); v += (g*g-v)(1-b2); var -= lr_t*m/(sqrt(v)+eps). */
+int rec_adam_dense_f32(float* var, float* m, float* v, const float* g, int64_t n, int64_t t, float lr,
+                       float b1, float b2, float eps, void* stream);
+/* Keras sparse apply = DENSE SWEEP: m*=b1, v*=b2 on all V rows, m[ids]+=(1-b1)g, v[ids]+=(1-b2)g^2, then
+ * var -= lr_t*m/(sqrt(v)+eps) on all V rows.  (uniq_ids, g_rows, n_uniq) as produced by the dedup above
+ * (cap = allocated rows of uniq_ids/g_rows).  side: workspace of cap*3*E floats. */
+int rec_adam_sparse_keras_f32(float* var, float* m, float* v, int64_t V, int E, const int64_t* uniq_ids,
+                              const float* g_rows, const int64_t* n_uniq, int64_t cap, float* side,
+                              int64_t t, float lr, float b1, float b2, float eps, void* stream);
+/* 'lazy' variant (NOT reference semantics): only the touched rows decay and move. */
+int rec_adam_rows_f32(float* var, float* m, float* v, int64_t V, int E, const int64_t* uniq_ids,
+                      const float* g_rows, const int64_t* n_uniq, int64_t cap, int64_t t, float lr,
+                      float b1, float b2, float eps, void* stream);
+
+/* ---- (e) row-wise block sharding of a table (no reference counterpart).
+ * owner = id / rows_per_shard.  perm[n]: positions grouped by owner, ascending inside a group;
+ * send_counts[n_shard] (int64); local_ids[n] = ids[perm] - owner*rows_per_shard. */
+size_t rec_shard_bucketize_workspace_bytes(int64_t n, int n_shard);
+int rec_shard_bucketize_i64(const int64_t* ids, int64_t n, int64_t rows_per_shard, int n_shard,
+                            int64_t* perm, int64_t* send_counts, int64_t* local_ids, int* oob_flag,
+                            void* workspace, size_t workspace_bytes, void* stream);
+/* out[perm[i], :] = in[i, :]   (inverse permutation of received rows) and its transpose */
+int rec_permute_rows_f32(const float* in, const int64_t* perm, int64_t n, int E, int scatter, float* out,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355REC_H */
