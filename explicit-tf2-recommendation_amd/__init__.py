@@ -8,5 +8,7 @@ reference's Layer / ModelManager interface on top.  Import name: ``explicit_tf2_
 """
 from . import _lib  # noqa: F401  (raises if the HIP library is missing: there is no fallback)
 from . import ops  # noqa: F401
+from . import functional  # noqa: F401
+from . import layers  # noqa: F401
 
-__all__ = ["ops"]
+__all__ = ["ops", "functional", "layers"]

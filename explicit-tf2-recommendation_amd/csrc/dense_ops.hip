@@ -27,6 +27,33 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(int act, const float* __re
   dpre[t] = g;
 }
 
+__global__ __launch_bounds__(256) void act_fwd_kernel(int act, const float* __restrict__ x, const float* __restrict__ x2, float* __restrict__ y,
+                                                      int64_t n) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  float v = x[t];
+  if (x2) v += x2[t];
+  switch (act) {
+    case REC_ACT_RELU: v = fmaxf(v, 0.f); break;
+    case REC_ACT_SIGMOID: v = sigmoid_acc(v); break;
+    case REC_ACT_TANH: v = tanhf(v); break;
+    default: break;
+  }
+  y[t] = v;
+}
+
+// MatrixCrossLayer backward, elementwise part of one layer: H = G (.) X0 ; dX0 (+)= G (.) U
+__global__ __launch_bounds__(256) void cross_mat_bwd_elem_kernel(const float* __restrict__ g, const float* __restrict__ x0,
+                                                                 const float* __restrict__ u, float* __restrict__ h,
+                                                                 float* __restrict__ gx0, int accumulate, int64_t n) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  float gg = g[t];
+  h[t] = gg * x0[t];
+  float a = accumulate ? gx0[t] : 0.f;
+  gx0[t] = a + gg * u[t];
+}
+
 // out[j] = sum_i X[i,j]: 32 columns x 8 row lanes per workgroup, fixed summation order.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int64_t M, int64_t N, int64_t ldx,
                                                      float* __restrict__ out) {
@@ -398,6 +425,26 @@ extern "C" int rec_act_bwd_f32(int act, const float* post, const float* dpost, f
   if (n == 0) return REC_OK;
   hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, as_stream(stream), act, post,
                      dpost, dpre, n);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_act_fwd_f32(int act, const float* x, const float* x2, float* y, int64_t n, void* stream) {
+  if (n < 0 || act < REC_ACT_NONE || act > REC_ACT_TANH) return REC_E_ARG;
+  if (n == 0) return REC_OK;
+  if (!x || !y) return REC_E_ARG;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, as_stream(stream), act, x, x2, y, n);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_crossnet_mat_bwd_elem_f32(const float* g, const float* x0, const float* u, float* h, float* gx0,
+                                             int accumulate, int64_t n, void* stream) {
+  if (n < 0) return REC_E_ARG;
+  if (n == 0) return REC_OK;
+  if (!g || !x0 || !u || !h || !gx0) return REC_E_ARG;
+  hipLaunchKernelGGL(cross_mat_bwd_elem_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, as_stream(stream), g,
+                     x0, u, h, gx0, accumulate, n);
   REC_LAUNCH_CHECK();
   return REC_OK;
 }

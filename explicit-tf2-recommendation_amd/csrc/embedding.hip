@@ -28,8 +28,9 @@ __global__ __launch_bounds__(256) void index_pack_kernel(ColPtrs cols, int F, in
 
 extern "C" int rec_index_pack_i64(const int64_t* const* cols_host, int F, int64_t rows, int64_t* X,
                                   int64_t ldx, int64_t col0, void* stream) {
-  if (!cols_host || !X || F <= 0 || rows < 0 || ldx < col0 + F) return REC_E_ARG;
+  if (!cols_host || F <= 0 || rows < 0 || ldx < col0 + F) return REC_E_ARG;
   if (rows == 0) return REC_OK;
+  if (!X) return REC_E_ARG;
   for (int f0 = 0; f0 < F; f0 += REC_MAX_COLS) {
     int nf = F - f0 < REC_MAX_COLS ? F - f0 : REC_MAX_COLS;
     ColPtrs cp;
@@ -84,8 +85,9 @@ __global__ __launch_bounds__(256) void gather_scalar_kernel(const float* __restr
 
 extern "C" int rec_emb_gather_f32(const float* table, int64_t V, int E, const int64_t* idx, int64_t n,
                                   float* out, int* oob_flag, void* stream) {
-  if (!table || !idx || !out || V <= 0 || E <= 0 || n < 0) return REC_E_ARG;
+  if (V <= 0 || E <= 0 || n < 0) return REC_E_ARG;
   if (n == 0) return REC_OK;
+  if (!table || !idx || !out) return REC_E_ARG;
   if (E % 4 == 0) {
     int lpr = E / 4;
     hipLaunchKernelGGL(gather_vec4_kernel, dim3((unsigned)ceil_div64(n * lpr, 256)), dim3(256), 0,
@@ -209,9 +211,10 @@ __global__ __launch_bounds__(256) void emb_fm_fwd_gen_kernel(
 extern "C" int rec_emb_fm_fwd_f32(const float* embed, const float* w, const float* bias, int64_t V, int E,
                                   const int64_t* idx, int64_t B, int F, float* z, float* prob, float* emb_out,
                                   float* sumvec, int* oob_flag, void* stream) {
-  if (!embed || !w || !bias || !idx || V <= 0 || E <= 0 || B < 0 || F <= 0) return REC_E_ARG;
+  if (V <= 0 || E <= 0 || B < 0 || F <= 0) return REC_E_ARG;
   if (E > 256) return REC_E_UNSUPPORTED;
   if (B == 0) return REC_OK;
+  if (!embed || !w || !bias || !idx) return REC_E_ARG;
   switch (E) {
     case 4: FWD_VEC(1); break;
     case 8: FWD_VEC(2); break;
@@ -288,8 +291,9 @@ __global__ __launch_bounds__(256) void emb_fm_bwd_vals_vec_kernel(
 extern "C" int rec_emb_fm_bwd_vals_f32(const float* embed, int64_t V, int E, const int64_t* idx, int64_t B,
                                        int F, const float* gz, const float* sumvec, const float* emb_rows,
                                        const float* extra, float* dvals, void* stream) {
-  if ((!embed && !emb_rows) || !idx || !gz || !sumvec || !dvals || E <= 0 || F <= 0 || B < 0) return REC_E_ARG;
+  if (E <= 0 || F <= 0 || B < 0) return REC_E_ARG;
   if (B == 0) return REC_OK;
+  if ((!embed && !emb_rows) || !idx || !gz || !sumvec || !dvals) return REC_E_ARG;
   if (E % 4 == 0) {
     int lpr = E / 4;
     hipLaunchKernelGGL(emb_fm_bwd_vals_vec_kernel, dim3((unsigned)ceil_div64(B * F * lpr, 256)), dim3(256), 0,

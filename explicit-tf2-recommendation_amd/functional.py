@@ -1,0 +1,207 @@
+"""torch.autograd.Function wrappers: forward and backward of each op are HIP kernels called through the C ABI
+(ops.py).  Embedding tables receive their gradient the way TF's GradientTape delivers it -- as an
+IndexedSlices-like sparse gradient -- here already de-duplicated (sorted unique ids + summed rows) and wrapped
+as an uncoalesced torch sparse COO tensor whose padded tail points at a valid id with zero rows, so no
+host synchronisation is needed to learn the unique count.
+"""
+import torch
+
+from . import ops
+
+
+class SparseRowGrad:
+    """(uniq_ids [cap], rows [cap,E], n_uniq [1]) as produced by ops.DedupPlan; what the fused optimizers eat."""
+
+    def __init__(self, uniq_ids, rows, n_uniq, shape):
+        self.uniq_ids, self.rows, self.n_uniq, self.shape = uniq_ids, rows, n_uniq, shape
+
+    def to_sparse(self):
+        return torch.sparse_coo_tensor(self.uniq_ids[: self.rows.shape[0]].unsqueeze(0), self.rows, self.shape)
+
+
+def _sparse_grad(plan, vals, E, shape, row_div=1):
+    rows = plan.segment_sum(vals, E, row_div)
+    return SparseRowGrad(plan.uniq_ids, rows, plan.n_uniq, shape).to_sparse()
+
+
+class Gather(torch.autograd.Function):
+    """Embedding(V,E)(X): K2.  Backward: sparse row gradient (K4)."""
+
+    @staticmethod
+    def forward(ctx, table, X, oob):
+        out = ops.emb_gather(table, X, oob)
+        ctx.save_for_backward(X)
+        ctx.shape = tuple(table.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (X,) = ctx.saved_tensors
+        V, E = ctx.shape
+        plan = ops.DedupPlan(X, V)
+        return _sparse_grad(plan, g.contiguous().reshape(-1, E), E, (V, E)), None, None
+
+
+class EmbFM(torch.autograd.Function):
+    """Fused w(X), embed(X), FM first + second order (K2+K3).  Returns z [B] and, for DeepFM, the gathered
+    rows [B,F,E] that feed the DNN part.  Backward builds the IndexedSlices values (FM term + whatever came
+    back through the rows) and de-duplicates once for both tables."""
+
+    @staticmethod
+    def forward(ctx, embed, w, bias, X, want_rows, oob):
+        z, _, rows, S = ops.emb_fm_fwd(embed, w, bias, X, want_rows=want_rows, oob=oob)
+        ctx.save_for_backward(embed, X, S, rows if want_rows else None)
+        if not want_rows:
+            rows = torch.empty(0, dtype=torch.float32, device=embed.device)
+            ctx.mark_non_differentiable(rows)
+        return z, rows
+
+    @staticmethod
+    def backward(ctx, gz, grows):
+        embed, X, S, rows = ctx.saved_tensors
+        V, E = embed.shape
+        B, F = X.shape
+        if gz is None:
+            gz = torch.zeros(B, dtype=torch.float32, device=embed.device)
+        gz = gz.contiguous()
+        extra = grows.contiguous() if (grows is not None and rows is not None) else None
+        vals = ops.emb_fm_bwd_vals(embed, X, gz, S, rows, extra)
+        plan = ops.DedupPlan(X, V)
+        g_embed = _sparse_grad(plan, vals, E, (V, E))
+        g_w = _sparse_grad(plan, gz.reshape(B, 1), 1, (V, 1), row_div=F)
+        g_bias = ops.colsum(gz.reshape(B, 1))
+        return g_embed, g_w, g_bias, None, None, None
+
+
+class LinearAct(torch.autograd.Function):
+    """act(x @ K + b): MatMul + BiasAdd + activation of MLPLayer / Dense (K5) on the fp32 matrix cores."""
+
+    @staticmethod
+    def forward(ctx, x, K, b, act):
+        x = x.contiguous()
+        if b is not None:
+            y = ops.gemm(x, K, epi=ops.EPI_OF_ACT[act], bias=b)
+        else:
+            y = ops.gemm(x, K)
+            if act != ops.ACT_NONE:
+                raise NotImplementedError("activation without bias")
+        ctx.save_for_backward(x, K, y)
+        ctx.act = act
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, K, y = ctx.saved_tensors
+        gy = gy.contiguous()
+        dpre = ops.act_bwd(ctx.act, y, gy) if ctx.act != ops.ACT_NONE else gy
+        M, Kd = x.shape
+        N = K.shape[1]
+        gx = ops.gemm(dpre, K, transB=True) if ctx.needs_input_grad[0] else None
+        gK = ops.gemm(x, dpre, transA=True, split_k=ops.split_k_for(M, Kd, N))
+        gb = ops.colsum(dpre) if ctx.has_bias else None
+        return gx, gK, gb, None
+
+
+class CrossVec(torch.autograd.Function):
+    """CrossLayer (3.DCN/CustomLayers.py:195-203).  w, b: [L, D]."""
+
+    @staticmethod
+    def forward(ctx, x0, w, b):
+        x0 = x0.contiguous()
+        y, xs = ops.crossnet_vec_fwd(x0, w.contiguous(), b.contiguous(), save=True)
+        ctx.save_for_backward(x0, w, xs)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x0, w, xs = ctx.saved_tensors
+        gx0, dw, db = ops.crossnet_vec_bwd(x0, w.contiguous(), xs, gy.contiguous())
+        return gx0, dw, db
+
+
+class CrossMat(torch.autograd.Function):
+    """MatrixCrossLayer (3.DCN/CustomLayers.py:297-305): x_{l+1} = x0 * (x_l W_l^T + b_l) + x_l, one MFMA GEMM
+    per layer with the elementwise part fused into its epilogue.  W: [L, D, D], b: [L, D]."""
+
+    @staticmethod
+    def forward(ctx, x0, W, b):
+        x0 = x0.contiguous()
+        L = W.shape[0]
+        xs = [x0]
+        for l in range(L):
+            xs.append(ops.gemm(xs[-1], W[l], transB=True, epi=ops.EPI_CROSS, bias=b[l], e0=x0, e1=xs[-1]))
+        ctx.save_for_backward(x0, W, b, *xs[:-1])
+        return xs[-1]
+
+    @staticmethod
+    def backward(ctx, gy):
+        x0, W, b = ctx.saved_tensors[:3]
+        xs = ctx.saved_tensors[3:]
+        L = W.shape[0]
+        B, D = x0.shape
+        g = gy.contiguous()
+        gx0 = torch.empty_like(x0)
+        dW = torch.empty_like(W)
+        db = torch.empty_like(b)
+        for l in range(L - 1, -1, -1):
+            xl = xs[l]
+            # U_l = x_l W_l^T + b_l is recomputed (one GEMM) instead of being kept from the forward
+            u = ops.gemm(xl, W[l], transB=True, epi=ops.EPI_BIAS, bias=b[l])
+            h = ops.crossnet_mat_bwd_elem(g, x0, u, gx0, accumulate=(l != L - 1))   # H = G(.)X0 ; dX0 += G(.)U
+            ops.gemm(h, xl, transA=True, split_k=ops.split_k_for(B, D, D), out=dW[l])
+            ops.colsum(h, out=db[l])
+            g = ops.gemm(h, W[l], epi=ops.EPI_ADD, e1=g)                             # dX_l = G + H W
+        if L == 0:
+            return g, dW, db
+        ops.axpby(1.0, g, 1.0, gx0)                                                  # x_0 is also layer 0's input
+        return gx0, dW, db
+
+
+class Cosine(torch.autograd.Function):
+    """(1 + keras cosine_similarity(u, i))/2 = (1 - cos)/2  (2.FM/CustomLayers.py:233-234)."""
+
+    @staticmethod
+    def forward(ctx, u, i):
+        u, i = u.contiguous(), i.contiguous()
+        ctx.save_for_backward(u, i)
+        return ops.cosine_fwd(u, i)
+
+    @staticmethod
+    def backward(ctx, g):
+        u, i = ctx.saved_tensors
+        return ops.cosine_bwd(u, i, g.contiguous())
+
+
+class KerasBCE(torch.autograd.Function):
+    """reduce_sum(BinaryCrossentropy()(y, p)) on probabilities (2.FM/ModelManager.py:100,175)."""
+
+    @staticmethod
+    def forward(ctx, p, y):
+        loss, dp, _ = ops.bce_fwd_bwd(y, p.contiguous(), want_dp=True)
+        ctx.save_for_backward(dp)
+        ctx.shape = p.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dp,) = ctx.saved_tensors
+        return (dp * g).reshape(ctx.shape), None
+
+
+class Sigmoid(torch.autograd.Function):
+    """tf.nn.sigmoid head (2.FM/CustomLayers.py:155,305)."""
+
+    @staticmethod
+    def forward(ctx, z, z2=None):
+        """sigmoid(z + z2): z2 is the optional second addend (fm_part + dnn_part)."""
+        y = ops.act_fwd(ops.ACT_SIGMOID, z.contiguous(), z2.contiguous().reshape(z.shape) if z2 is not None else None)
+        ctx.save_for_backward(y)
+        ctx.shape2 = z2.shape if z2 is not None else None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        gz = ops.act_bwd(ops.ACT_SIGMOID, y, g.contiguous())
+        return gz, (gz.reshape(ctx.shape2) if ctx.shape2 is not None else None)

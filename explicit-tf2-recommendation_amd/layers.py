@@ -1,0 +1,404 @@
+"""Mirror of the reference's CustomLayers.py for the hot path -- same class names, constructor keywords,
+dict-in / dict-out ``__call__`` and error behaviour -- with every op executed by the HIP kernels of
+libmi355rec.so (through functional.py / ops.py).  Reference classes and the lines they follow:
+
+  MLPLayer                      2.FM/CustomLayers.py:15-84   (default activation None; 'relu' in the 3.DCN/5.DIN copies)
+  FMRankingLayer                2.FM/CustomLayers.py:87-157
+  DSSMSingleTowerLayer          2.FM/CustomLayers.py:159-206
+  DSSMTwoTowerRetrievalLayer    2.FM/CustomLayers.py:208-239
+  DeepFMRankingLayer            2.FM/CustomLayers.py:241-308
+  DenseLayer                    3.DCN/CustomLayers.py:153-167
+  CrossLayer                    3.DCN/CustomLayers.py:170-203
+  DeepCrossNetworkLayer         3.DCN/CustomLayers.py:206-269
+  MatrixCrossLayer              3.DCN/CustomLayers.py:272-305
+
+Parameters are named after the TF checkpoint keys (``embed.embeddings``, ``w.embeddings``, ``bias``,
+``MLP_layer1.kernel_0`` ...), so a TensorBundle checkpoint maps onto ``state_dict()`` by name.
+Index tensors may be int64 ``[B,1]`` (ModelManager path) or ``[B]`` (direct layer call); out-of-range ids raise
+IndexError when ``check_ids`` is on (the reference raises InvalidArgumentError on CPU).
+"""
+import math
+
+import torch
+
+from . import functional as Fn
+from . import ops
+
+
+# ---------------------------------------------------------------------------------------------------
+# initialisers (Keras defaults)
+# ---------------------------------------------------------------------------------------------------
+
+_init_gen = torch.Generator(device="cpu")
+_init_gen.manual_seed(1234)
+
+
+def set_init_seed(seed):
+    _init_gen.manual_seed(seed)
+
+
+def _uniform(shape, lim):
+    return (torch.rand(shape, generator=_init_gen) * 2 - 1) * lim
+
+
+def glorot_uniform(shape):
+    fan_in, fan_out = (shape[0], shape[1]) if len(shape) == 2 else (shape[0], shape[0])
+    return _uniform(shape, math.sqrt(6.0 / (fan_in + fan_out)))
+
+
+def _initializer(name):
+    if callable(name):
+        return name
+    table = {"glorot_uniform": glorot_uniform, "zeros": lambda s: torch.zeros(s),
+             "random_normal": lambda s: torch.randn(s, generator=_init_gen) * 0.05,
+             "uniform": lambda s: _uniform(s, 0.05)}
+    if name not in table:
+        raise ValueError("Unknown initializer: %r" % (name,))
+    return table[name]
+
+
+def _activation_code(activation):
+    if activation not in ops.ACT_CODE:
+        raise ValueError("Unknown activation function: %r" % (activation,))
+    return ops.ACT_CODE[activation]
+
+
+class Layer(torch.nn.Module):
+    """Keras-Layer conveniences on top of torch.nn.Module."""
+
+    check_ids = True            # debug-mode bounds check: one 4-byte device->host read per call
+
+    @property
+    def trainable_variables(self):
+        return [p for p in self.parameters() if p.requires_grad]
+
+    def _device(self):
+        for p in self.parameters():
+            return p.device
+        return torch.device("cuda")
+
+    def _raise_if_oob(self, flag):
+        if flag is not None and int(flag.item()) != 0:
+            raise IndexError("embedding id out of range [0, feature_dims)")
+
+
+def assemble_index(inputs, feature_names):
+    """expand_dims(rank-1) + concat(axis=1)  (2.FM/CustomLayers.py:138-144) -> X [B,F] int64, on the GPU."""
+    cols = []
+    for name in feature_names:
+        t = inputs[name]
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(t)
+        if t.dtype != torch.int64:
+            t = t.to(torch.int64)
+        if t.dim() not in (1, 2) or (t.dim() == 2 and t.shape[1] != 1):
+            raise ValueError("feature %r must have shape [B] or [B,1], got %s" % (name, tuple(t.shape)))
+        if not t.is_cuda:
+            t = t.cuda()
+        cols.append(t.contiguous())
+    return ops.index_pack(cols)
+
+
+class Embedding(Layer):
+    """tf.keras.layers.Embedding(V, E): table ``embeddings`` ~ U(-0.05, 0.05)."""
+
+    def __init__(self, input_dim, output_dim, embeddings_regularizer=None):
+        super().__init__()
+        # the "l2" regulariser of the reference lands in layer.losses, which its train loop never adds
+        # (2.FM/ModelManager.py:175): kept for signature compatibility, no effect on gradients.
+        self.embeddings_regularizer = embeddings_regularizer
+        self.embeddings = torch.nn.Parameter(_uniform((input_dim, output_dim), 0.05))
+
+    def forward(self, X, oob=None):
+        return Fn.Gather.apply(self.embeddings, X, oob)
+
+
+class MLPLayer(Layer):
+    """MatMul + BiasAdd + activation on EVERY layer (2.FM/CustomLayers.py:72-84)."""
+
+    def __init__(self, units, activation=None, use_bias=True, is_batch_norm=False, is_dropput=0,
+                 kernel_initializer="glorot_uniform", bias_initializer="zeros", input_dim=None, **kwargs):
+        super().__init__()
+        self.units = [units] if not isinstance(units, list) else units
+        if len(self.units) <= 0:
+            raise ValueError("Received an invalid value for `units`, expected a positive integer, got %r." % (units,))
+        if is_batch_norm:
+            raise NotImplementedError("is_batch_norm=True is never used on the hot path")
+        self.use_bias = use_bias
+        self.is_dropout = is_dropput          # can never fire in the reference (is_train is never passed)
+        self.activation = activation
+        self._act = _activation_code(activation)
+        self._kinit = _initializer(kernel_initializer)
+        self._binit = _initializer(bias_initializer)
+        self.built = False
+        if input_dim is not None:
+            self.build(input_dim)
+
+    def build(self, last_dim):
+        dims = [int(last_dim)] + list(self.units)
+        for i in range(len(dims) - 1):
+            self.register_parameter("kernel_%d" % i, torch.nn.Parameter(self._kinit((dims[i], dims[i + 1]))))
+            if self.use_bias:
+                self.register_parameter("bias_%d" % i, torch.nn.Parameter(self._binit((dims[i + 1],))))
+        self.built = True
+
+    def forward(self, inputs, is_train=False):
+        if not self.built:
+            if inputs.shape[-1] is None:
+                raise ValueError("The last dimension of the inputs to `Dense` should be defined. Found `None`.")
+            self.build(inputs.shape[-1])
+            self.to(inputs.device)
+        x = inputs
+        for i in range(len(self.units)):
+            b = getattr(self, "bias_%d" % i) if self.use_bias else None
+            x = Fn.LinearAct.apply(x, getattr(self, "kernel_%d" % i), b, self._act)
+        return x
+
+
+class FMRankingLayer(Layer):
+    def __init__(self, feature_names=["item_tag1", "item_tag2", "item_tag3"], feature_dims=20, embedding_dims=16,
+                 **kwargs):
+        super().__init__()
+        self.feature_names = feature_names
+        self.feature_dims = feature_dims
+        self.embedding_dims = embedding_dims
+        self.bias = torch.nn.Parameter(glorot_uniform((1,)))          # Keras default for a float weight
+        self.embed = Embedding(feature_dims, embedding_dims, embeddings_regularizer="l2")
+        self.w = Embedding(feature_dims, 1, embeddings_regularizer="l2")
+
+    def forward(self, inputs):
+        X = assemble_index(inputs, self.feature_names)
+        flag = ops.new_flag(X.device) if self.check_ids else None
+        z, _ = Fn.EmbFM.apply(self.embed.embeddings, self.w.embeddings, self.bias, X, False, flag)
+        self._raise_if_oob(flag)
+        output = Fn.Sigmoid.apply(z).reshape(-1, 1)
+        return {"output": output}
+
+
+class DeepFMRankingLayer(Layer):
+    def __init__(self, feature_names=["user_tag0", "user_tag1", "item_tag1", "item_tag2", "item_tag3"],
+                 feature_dims=20, embedding_dims=16, mlp_dims=[32, 8], **kwargs):
+        super().__init__()
+        self.feature_names = feature_names
+        self.feature_dims = feature_dims
+        self.embedding_dims = embedding_dims
+        self.mlp_dims = mlp_dims
+        self.bias = torch.nn.Parameter(glorot_uniform((1,)))
+        self.embed = Embedding(feature_dims, embedding_dims, embeddings_regularizer="l2")
+        self.w = Embedding(feature_dims, 1, embeddings_regularizer="l2")
+        self.MLP_layer1 = MLPLayer(units=list(mlp_dims), activation="relu",
+                                   input_dim=len(feature_names) * embedding_dims)
+        self.MLP_layer2 = MLPLayer(units=[1], input_dim=list(mlp_dims)[-1])
+
+    def forward(self, inputs):
+        X = assemble_index(inputs, self.feature_names)
+        flag = ops.new_flag(X.device) if self.check_ids else None
+        fm_part, rows = Fn.EmbFM.apply(self.embed.embeddings, self.w.embeddings, self.bias, X, True, flag)
+        self._raise_if_oob(flag)
+        dense_embedding = rows.reshape(rows.shape[0], -1)             # Flatten(): field-major, dim-minor
+        dnn_part = self.MLP_layer2(self.MLP_layer1(dense_embedding))  # [B,1]
+        return {"output": Fn.Sigmoid.apply(dnn_part, fm_part)}         # sigmoid(fm_part + dnn_part), [B,1]
+
+
+class DSSMSingleTowerLayer(Layer):
+    def __init__(self, feature_names=["item_tag1", "item_tag2", "item_tag3"], feature_dims=20, embedding_dims=8,
+                 mlp_dims=[64, 32], final_dim=8, **kwargs):
+        super().__init__()
+        self.feature_names = feature_names
+        self.feature_dims = feature_dims
+        self.embedding_dims = embedding_dims
+        self.mlp_dims = mlp_dims
+        self.final_dim = final_dim
+        self.embed = Embedding(feature_dims, embedding_dims, embeddings_regularizer="l2")
+        self.mlp = MLPLayer(units=list(mlp_dims), activation="relu", input_dim=len(feature_names) * embedding_dims)
+        self.final = MLPLayer(units=[final_dim], activation=None, input_dim=list(mlp_dims)[-1])
+
+    def forward(self, inputs):
+        # the reference accepts [B,1] (model path) and, through an exception-driven reshape, [B] (direct call,
+        # 2.FM/CustomLayers.py:188-194): both are handled explicitly here
+        X = assemble_index(inputs, self.feature_names)
+        flag = ops.new_flag(X.device) if self.check_ids else None
+        e = self.embed(X, flag)
+        self._raise_if_oob(flag)
+        x = e.reshape(e.shape[0], -1)
+        x = self.final(self.mlp(x))
+        return {"user_id": inputs.get("user_id", None), "item_id": inputs.get("item_id", None), "output": x}
+
+
+class DSSMTwoTowerRetrievalLayer(Layer):
+    def __init__(self, u_feature_names=["user_tag1", "user_tag2"],
+                 i_feature_names=["item_tag1", "item_tag2", "item_tag3"], u_feature_dims=20, i_feature_dims=20,
+                 u_embedding_dims=8, i_embedding_dims=8, u_mlp_dims=[64, 32], i_mlp_dims=[64, 32], final_dim=8,
+                 **kwargs):
+        super().__init__()
+        self.u_tower = DSSMSingleTowerLayer(feature_names=u_feature_names, feature_dims=u_feature_dims,
+                                            embedding_dims=u_embedding_dims, mlp_dims=u_mlp_dims, final_dim=final_dim)
+        self.i_tower = DSSMSingleTowerLayer(feature_names=i_feature_names, feature_dims=i_feature_dims,
+                                            embedding_dims=i_embedding_dims, mlp_dims=i_mlp_dims, final_dim=final_dim)
+
+    def forward(self, inputs):
+        u_embedding = self.u_tower(inputs)["output"]
+        i_embedding = self.i_tower(inputs)["output"]
+        similarity = Fn.Cosine.apply(u_embedding, i_embedding)        # (1 - cos)/2, shape [B]
+        return {"user_embedding": u_embedding, "item_embedding": i_embedding, "output": similarity}
+
+
+# ---------------------------------------------------------------------------------------------------
+# 3.DCN
+# ---------------------------------------------------------------------------------------------------
+
+class Dense(Layer):
+    """tf.keras.layers.Dense(units, activation): ``kernel`` glorot-uniform, ``bias`` zeros."""
+
+    def __init__(self, units, activation=None, input_dim=None):
+        super().__init__()
+        self.units = units
+        self._act = _activation_code(activation)
+        self.built = False
+        if input_dim is not None:
+            self.build(input_dim)
+
+    def build(self, last_dim):
+        self.kernel = torch.nn.Parameter(glorot_uniform((int(last_dim), self.units)))
+        self.bias = torch.nn.Parameter(torch.zeros(self.units))
+        self.built = True
+
+    def forward(self, x):
+        if not self.built:
+            self.build(x.shape[-1])
+            self.to(x.device)
+        return Fn.LinearAct.apply(x, self.kernel, self.bias, self._act)
+
+
+class DenseLayer(Layer):
+    def __init__(self, units, activation, input_dim=None):
+        super().__init__()
+        dims = [input_dim] + list(units)
+        self.hidden_layer = torch.nn.ModuleList(
+            [Dense(u, activation=activation, input_dim=dims[i]) for i, u in enumerate(units)])
+
+    def forward(self, inputs, **kwargs):
+        x = inputs
+        for layer in self.hidden_layer:
+            x = layer(x)
+        return x
+
+
+class _CrossBase(Layer):
+    def __init__(self, layer_num, reg_w=1e-4, reg_b=1e-4, input_dim=None):
+        super().__init__()
+        self.layer_num = layer_num
+        self.reg_w = reg_w          # l2 regularisers never reach the loss in the reference's loop
+        self.reg_b = reg_b
+        self.built = False
+        if input_dim is not None:
+            self.build(input_dim)
+
+    def _maybe_build(self, x):
+        if not self.built:
+            self.build(x.shape[1])
+            self.to(x.device)
+
+
+class CrossLayer(_CrossBase):
+    """x_{l+1} = x0 * (x_l^T w_l) + b_l + x_l; w_l, b_l: [D,1] (w ~ N(0,0.05), b = 0)."""
+
+    def build(self, D):
+        for i in range(self.layer_num):
+            self.register_parameter("w%d" % i, torch.nn.Parameter(torch.randn((D, 1), generator=_init_gen) * 0.05))
+            self.register_parameter("b%d" % i, torch.nn.Parameter(torch.zeros((D, 1))))
+        self.built = True
+
+    def forward(self, inputs, **kwargs):
+        self._maybe_build(inputs)
+        w = torch.cat([getattr(self, "w%d" % i).reshape(1, -1) for i in range(self.layer_num)], dim=0)
+        b = torch.cat([getattr(self, "b%d" % i).reshape(1, -1) for i in range(self.layer_num)], dim=0)
+        return Fn.CrossVec.apply(inputs, w, b)
+
+
+class MatrixCrossLayer(_CrossBase):
+    """x_{l+1} = x0 (.) (W_l x_l + b_l) + x_l; W_l: [D,D] ~ N(0,0.05), b_l: [D,1] = 0."""
+
+    def build(self, D):
+        for i in range(self.layer_num):
+            self.register_parameter("w%d" % i, torch.nn.Parameter(torch.randn((D, D), generator=_init_gen) * 0.05))
+            self.register_parameter("b%d" % i, torch.nn.Parameter(torch.zeros((D, 1))))
+        self.built = True
+
+    def forward(self, inputs, **kwargs):
+        self._maybe_build(inputs)
+        W = torch.stack([getattr(self, "w%d" % i) for i in range(self.layer_num)], dim=0)
+        b = torch.cat([getattr(self, "b%d" % i).reshape(1, -1) for i in range(self.layer_num)], dim=0)
+        return Fn.CrossMat.apply(inputs, W, b)
+
+
+class ConcatCols(torch.autograd.Function):
+    """tf.concat(axis=1) of 2-D fp32 blocks, by column-block copies."""
+
+    @staticmethod
+    def forward(ctx, *blocks):
+        widths = [b.shape[1] for b in blocks]
+        out = torch.empty((blocks[0].shape[0], sum(widths)), dtype=torch.float32, device=blocks[0].device)
+        c = 0
+        for b, w in zip(blocks, widths):
+            ops.copy_cols(b.contiguous(), out[:, c:c + w])
+            c += w
+        ctx.widths = widths
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        outs = []
+        c = 0
+        for w in ctx.widths:
+            blk = torch.empty((g.shape[0], w), dtype=torch.float32, device=g.device)
+            ops.copy_cols(g[:, c:c + w], blk)
+            outs.append(blk)
+            c += w
+        return tuple(outs)
+
+
+def _cont_block(inputs, names, device):
+    cols = []
+    for n in names:
+        t = inputs[n]
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(t)
+        t = t.to(device=device, dtype=torch.float32)
+        if t.dim() == 1:
+            t = t.unsqueeze(1)
+        cols.append(t.contiguous())
+    return cols
+
+
+class DeepCrossNetworkLayer(Layer):
+    def __init__(self, categorical_features=["uid", "iid", "utag1", "utag2", "utag3", "utag4", "itag1", "itag2",
+                                             "itag3", "itag4"],
+                 continuous_features=["itag4_origin", "itag4_square", "itag4_cube"], feature_dims=160000,
+                 embedding_dims=16, units=[64, 8], activation="relu", layer_num=3, reg_w=1e-4, reg_b=1e-4,
+                 type="vec"):
+        super().__init__()
+        D = len(continuous_features) + len(categorical_features) * embedding_dims
+        if type == "vec":
+            self.cross_layer = CrossLayer(layer_num, reg_w, reg_b, input_dim=D)
+        else:
+            self.cross_layer = MatrixCrossLayer(layer_num, reg_w, reg_b, input_dim=D)
+        self.dense_layer = DenseLayer(units, activation, input_dim=D)
+        self.embedding_layer = Embedding(feature_dims, embedding_dims)
+        self.categorical_features = categorical_features
+        self.continuous_features = continuous_features
+        self.output_layer = Dense(1, activation="sigmoid", input_dim=D + list(units)[-1])
+
+    def forward(self, inputs):
+        X = assemble_index(inputs, self.categorical_features)
+        flag = ops.new_flag(X.device) if self.check_ids else None
+        X_emb = self.embedding_layer(X, flag)
+        self._raise_if_oob(flag)
+        X_flatten = X_emb.reshape(X_emb.shape[0], -1)
+        cont = _cont_block(inputs, self.continuous_features, X.device)
+        _input = ConcatCols.apply(*cont, X_flatten)                   # continuous FIRST (:259)
+        cross_output = self.cross_layer(_input)
+        dnn_output = self.dense_layer(_input)
+        combine_output = ConcatCols.apply(cross_output, dnn_output)
+        return {"output": self.output_layer(combine_output)}

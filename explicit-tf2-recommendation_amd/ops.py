@@ -156,6 +156,21 @@ def gemm(A, B, transA=False, transB=False, epi=EPI_NONE, bias=None, e0=None, e1=
     return out
 
 
+def act_fwd(act, x, x2=None):
+    """y = act(x + x2)."""
+    y = torch.empty_like(x)
+    check(lib.rec_act_fwd_f32(act, _ptr(_f32(x, "x")), _ptr(x2), _ptr(y), x.numel(), _stream()), "rec_act_fwd_f32")
+    return y
+
+
+def crossnet_mat_bwd_elem(g, x0, u, gx0, accumulate):
+    """h = g*x0 (returned); gx0 (+)= g*u in place."""
+    h = torch.empty_like(g)
+    check(lib.rec_crossnet_mat_bwd_elem_f32(_ptr(_f32(g, "g")), _ptr(x0), _ptr(u), _ptr(h), _ptr(gx0),
+                                            int(accumulate), g.numel(), _stream()), "rec_crossnet_mat_bwd_elem_f32")
+    return h
+
+
 def act_bwd(act, post, dpost):
     out = torch.empty_like(dpost)
     check(lib.rec_act_bwd_f32(act, _ptr(_f32(post, "post")), _ptr(_f32(dpost, "dpost")), _ptr(out), post.numel(),
@@ -163,9 +178,10 @@ def act_bwd(act, post, dpost):
     return out
 
 
-def colsum(X):
+def colsum(X, out=None):
     M, N = X.shape
-    out = torch.empty(N, dtype=torch.float32, device=X.device)
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=X.device)
     check(lib.rec_colsum_f32(_ptr(X), M, N, X.stride(0), _ptr(out), _stream()), "rec_colsum_f32")
     return out
 

@@ -104,7 +104,14 @@ int rec_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const 
                  const float* e0, int64_t lde0, const float* e1, int64_t lde1, int split_k,
                  float* workspace, void* stream);
 
-/* elementwise helpers of the dense backward */
+/* ---- K6 backward, elementwise part of one MatrixCrossLayer layer: h = g*x0 ; gx0 = (accumulate ? gx0 : 0) + g*u
+ * (H = G (.) X0 feeds the dW and dX GEMMs; dX0 += G (.) U_l).  n = B*D. */
+int rec_crossnet_mat_bwd_elem_f32(const float* g, const float* x0, const float* u, float* h, float* gx0,
+                                  int accumulate, int64_t n, void* stream);
+
+/* elementwise helpers of the dense forward / backward */
+/* y = act(x + x2)  (x2 optional; tf.nn.sigmoid(fm_part + dnn_part), 2.FM/CustomLayers.py:155,305) */
+int rec_act_fwd_f32(int act, const float* x, const float* x2, float* y, int64_t n, void* stream);
 /* dpre = dpost * act'(post)   (in place allowed) */
 int rec_act_bwd_f32(int act, const float* post, const float* dpost, float* dpre, int64_t n, void* stream);
 /* out[j] = sum_i X[i,j]  (bias gradients), deterministic */

@@ -284,16 +284,25 @@ def test_cosine(ops, d):
 def test_bce(ops, n):
     r = H.rng(n)
     y = (r.uniform(size=(n, 1)) < 0.25).astype(np.float32)
-    p = r.uniform(size=(n, 1)).astype(np.float32)
-    if n > 2:
-        p[0], p[1] = 0.0, 1.0
+    p = r.uniform(0.005, 0.995, size=(n, 1)).astype(np.float32)
     loss, dp, dz = ops.bce_fwd_bwd(dev(y), dev(p), want_dp=True, want_dz=True)
     ref = L.bce_forward(y, p, np.float64)
     assert abs(loss.item() - ref) <= 1e-5 * max(1, abs(ref))
+    rdp = L.bce_backward(y, p, np.float64)[:, 0]
+    assert np.abs(dp.cpu().numpy() - rdp).max() <= 1e-5 * np.abs(rdp).max()
+    assert np.abs(dz.cpu().numpy() - rdp * p[:, 0] * (1 - p[:, 0])).max() <= 1e-5 * np.abs(rdp).max()
+
+
+def test_bce_saturated_matches_fp32_restatement(ops):
+    """p = 0 / 1 exercise the clip; 1 - (1 - 1e-7) is not 1e-7 in fp32, so the fp32 op-for-op
+    restatement (what TF computes) is the reference here, not fp64."""
+    y = np.array([[1], [0], [0], [1], [1]], np.float32)
+    p = np.array([[0.0], [1.0], [0.0], [1.0], [0.5]], np.float32)
+    loss, dp, _ = ops.bce_fwd_bwd(dev(y), dev(p), want_dp=True)
+    ref = L.bce_forward(y, p, np.float32)
+    assert abs(loss.item() - ref) <= 1e-5 * abs(ref)
     rdp = L.bce_backward(y, p, np.float32)[:, 0]
-    got = dp.cpu().numpy()
-    assert np.abs(got - rdp).max() <= 1e-5 * max(1e-30, np.abs(rdp).max())
-    assert np.abs(dz.cpu().numpy() - rdp * p[:, 0] * (1 - p[:, 0])).max() <= 1e-5 * max(1e-30, np.abs(rdp).max())
+    assert np.abs(dp.cpu().numpy() - rdp).max() <= 1e-5 * np.abs(rdp).max()
 
 
 def test_adam_dense_and_sparse(ops):
