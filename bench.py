@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: examples/sec, forward + backward, DeepFM 10M-vocab x 16d, batch 8192 per GPU
+(BASELINE.json `metric`), plus achieved HBM GB/s of the embedding-gather kernel against the gfx950 roofline
+and the CPU baseline (oracle/torch_ref.py, the op-for-op TF2-CPU stand-in) timed on the same box.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one train_loop iteration without the optimizer (2.FM/ModelManager.py:171-177): index assembly,
+fused gather + FM, DNN part, sigmoid, Keras BCE, and every gradient materialised (dense parameters as dense
+tensors, the two tables as sorted-unique row sums).  Inputs (26 int64 [B,1] feature tensors + the label, the
+DataGenerator contract) are resident in HBM before the timed region starts.  One JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+CFG = dict(workload="DeepFM fwd+bwd, 26 categorical fields, 10M-vocab x 16d, batch 8192 (BASELINE.json metric)",
+           vocab=10_000_000, fields=26, embedding_dims=16, mlp_dims=[32, 8], batch=8192)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--vocab", type=int, default=CFG["vocab"])
+    ap.add_argument("--batch", type=int, default=CFG["batch"])
+    ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly (no hipGraph replay)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--adam-steps", type=int, default=10, help="extra: full train steps with reference-exact Adam")
+    return ap.parse_args()
+
+
+def host_cores():
+    """Cores this process may actually use: the cgroup CPU quota when there is one (the GPU box gives a
+    16-CPU share of a 256-thread host), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(args, names, seconds):
+    """oracle/torch_ref.py DeepFM forward + BCE + backward (sparse table grads, de-duplicated) on the host
+    cores: the "TF2-CPU stand-in" of BASELINE.md section 2.  Bounded sample of the same workload."""
+    from oracle import torch_ref as T
+    from explicit_tf2_recommendation_amd import data
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    V, F, E, B = args.vocab, CFG["fields"], CFG["embedding_dims"], args.batch
+    g = torch.Generator().manual_seed(1234)
+    u = lambda *s: (torch.rand(*s, generator=g) - 0.5) * 0.1
+    dims = [F * E] + CFG["mlp_dims"]
+    p = {"embed": u(V, E).requires_grad_(), "w": u(V, 1).requires_grad_(), "bias": u(1).requires_grad_(),
+         "k1": [u(dims[i], dims[i + 1]).requires_grad_() for i in range(2)],
+         "b1": [torch.zeros(dims[i + 1]).requires_grad_() for i in range(2)],
+         "k2": [u(dims[-1], 1).requires_grad_()], "b2": [torch.zeros(1).requires_grad_()]}
+    leaves = [p["embed"], p["w"], p["bias"]] + p["k1"] + p["b1"] + p["k2"] + p["b2"]
+    gen = data.SyntheticGenerator(names, V, dist=args.dist, seed=0)
+    batches = []
+    for _ in range(2):
+        b = gen.batch(B)
+        batches.append(({k: torch.from_numpy(b[k]) for k in names}, torch.from_numpy(b["label"])))
+
+    def one(i):
+        ins, y = batches[i % len(batches)]
+        X = T.index_assemble(ins, names)
+        loss = T.keras_bce(y, T.deepfm_forward(p, X, sparse=True))
+        grads = torch.autograd.grad(loss, leaves)
+        return [gr.coalesce() if gr.is_sparse else gr for gr in grads]     # de-duplicated IndexedSlices
+
+    one(0)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one(n)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 200:
+            break
+    return {"value": n * B / el, "unit": "examples/s", "cores": cores, "kind": "port",
+            "sample": "%d fwd+bwd steps of the same DeepFM config (B=%d, V=%d) in %.1f s, torch-CPU eager "
+                      "op-for-op restatement (oracle/torch_ref.py), %d threads" % (n, B, V, el, cores)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    from explicit_tf2_recommendation_amd import layers, engine, data, ops
+
+    V, F, E, B = args.vocab, CFG["fields"], CFG["embedding_dims"], args.batch
+    names = ["C%d" % (i + 1) for i in range(F)]
+    layers.set_init_seed(1234)
+    layer = layers.DeepFMRankingLayer(feature_names=names, feature_dims=V, embedding_dims=E,
+                                      mlp_dims=CFG["mlp_dims"]).cuda()
+    gen = data.SyntheticGenerator(names, V, dist=args.dist, seed=rank)
+    n_batches = 4
+    batches = [data.to_device(gen.batch(B)) for _ in range(n_batches)]
+    step = engine.DeepFMTrainStep(layer, B, optimizer=None, use_graph=not args.no_graph)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(max(args.warmup, n_batches)):        # warm-up also captures one graph per resident batch
+        step(batches[i % n_batches])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(batches[i % n_batches])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if int(step.oob.item()) != 0:
+        raise SystemExit("out-of-range id seen by the gather kernel")
+    loss = float(step.loss.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    # ---- roofline of the dominant HBM kernel: the fused embedding gather + FM forward ------------------
+    # algorithmic bytes per launch: B*F*(8 + E*4 + 4) + B*4 = ids + embed rows + w scalars + logit
+    algo_bytes = B * F * (8 + E * 4 + 4) + B * 4
+    X = step.X
+    emb, w, bias = layer.embed.embeddings, layer.w.embeddings, layer.bias
+    reps = 100
+    import ctypes as C
+    from explicit_tf2_recommendation_amd._lib import lib, check
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    zbuf = torch.empty(B, dtype=torch.float32, device="cuda")
+
+    def launch_gather(n):
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for _ in range(n):
+            check(lib.rec_emb_fm_fwd_f32(vp(emb), vp(w), vp(bias), V, E, vp(X), B, F, vp(zbuf), None, None, None,
+                                         None, st), "rec_emb_fm_fwd_f32")
+
+    launch_gather(10)
+    torch.cuda.synchronize()
+    gg = torch.cuda.CUDAGraph()       # back-to-back launches replayed from a hipGraph: no host gaps
+    with torch.cuda.graph(gg):
+        launch_gather(reps)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    gg.replay()
+    torch.cuda.synchronize()
+    ev0.record()                      # events and the replay share torch's current stream
+    gg.replay()
+    ev1.record()
+    torch.cuda.synchronize()
+    kern_us = ev0.elapsed_time(ev1) * 1e3 / reps
+    achieved = algo_bytes / (kern_us * 1e-6) / 1e9
+    roofline = {"bound": "hbm", "kernel": "emb_fm_fwd_vec_kernel<4> (gather + FM, no row write-back)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": kern_us,
+                "timing": "HIP events around %d back-to-back launches on the launch stream" % reps}
+
+    extra = {}
+    if args.adam_steps > 0 and rank == 0:
+        st2 = engine.DeepFMTrainStep(layer, B, optimizer="keras_adam", lr=1e-3, use_graph=False)
+        for i in range(2):
+            st2(batches[i % n_batches])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.adam_steps):
+            st2(batches[i % n_batches])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / args.adam_steps
+        extra["train_step_keras_adam_ms"] = dt * 1e3
+        extra["train_step_keras_adam_examples_per_s"] = B / dt
+        extra["adam_sweep_bytes_per_step"] = 6 * (V * E + V) * 4
+
+    if rank == 0:
+        out = {"metric": "examples/sec fwd+bwd, DeepFM 10M-vocab x16d batch 8192", "value": value,
+               "unit": "examples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": CFG["workload"], "vocab": V, "fields": F, "embedding_dims": E,
+                          "mlp_dims": CFG["mlp_dims"], "batch_per_gpu": B, "id_distribution": args.dist,
+                          "parallelism": "1 process per GPU, independent replicas" if world > 1 else "single GPU",
+                          "hipgraph": not args.no_graph},
+               "roofline": roofline, "loss": loss}
+        out.update(extra)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, names, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,23 +54,35 @@ __global__ __launch_bounds__(256) void cross_mat_bwd_elem_kernel(const float* __
   gx0[t] = a + gg * u[t];
 }
 
-// out[j] = sum_i X[i,j]: 32 columns x 8 row lanes per workgroup, fixed summation order.
+// out[j] = sum_i X[i,j], two stages with a fixed summation order: stage 1 = (32 columns x 8 row lanes) per
+// workgroup over one of `nrb` row blocks -> part[rb][N]; stage 2 adds the row blocks in order.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int64_t M, int64_t N, int64_t ldx,
-                                                     float* __restrict__ out) {
+                                                     int64_t rows_per_block, float* __restrict__ part) {
   __shared__ float sh[8][33];
   int c = threadIdx.x & 31, r = threadIdx.x >> 5;
   int64_t col = (int64_t)blockIdx.x * 32 + c;
+  int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
   float acc = 0.f;
   if (col < N)
-    for (int64_t i = r; i < M; i += 8) acc += X[i * ldx + col];
+    for (int64_t i = r0 + r; i < r1; i += 8) acc += X[i * ldx + col];
   sh[r][c] = acc;
   __syncthreads();
   if (r == 0 && col < N) {
     float s = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) s += sh[q][c];
-    out[col] = s;
+    part[(int64_t)blockIdx.y * N + col] = s;
   }
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nrb, int64_t N,
+                                                           float* __restrict__ out) {
+  int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (col >= N) return;
+  float s = 0.f;
+  for (int q = 0; q < nrb; ++q) s += part[(int64_t)q * N + col];
+  out[col] = s;
 }
 
 __global__ __launch_bounds__(256) void axpby_kernel(float a, const float* __restrict__ x, float b,
@@ -449,11 +461,30 @@ extern "C" int rec_crossnet_mat_bwd_elem_f32(const float* g, const float* x0, co
   return REC_OK;
 }
 
-extern "C" int rec_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx, float* out, void* stream) {
+static inline int colsum_row_blocks(int64_t M) {
+  int64_t nrb = ceil_div64(M, 128);
+  return (int)(nrb < 1 ? 1 : (nrb > 128 ? 128 : nrb));
+}
+
+extern "C" size_t rec_colsum_workspace_bytes(int64_t M, int64_t N) {
+  return sizeof(float) * (size_t)colsum_row_blocks(M) * (size_t)(N > 0 ? N : 1);
+}
+
+extern "C" int rec_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx, float* out, float* workspace,
+                              void* stream) {
   if (!X || !out || M < 0 || N <= 0 || ldx < N) return REC_E_ARG;
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div64(N, 32)), dim3(256), 0, as_stream(stream), X, M, N, ldx,
-                     out);
+  int nrb = colsum_row_blocks(M);
+  if (nrb > 1 && !workspace) return REC_E_WORKSPACE;
+  int64_t rpb = ceil_div64(M > 0 ? M : 1, nrb);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div64(N, 32), (unsigned)nrb), dim3(256), 0, st, X, M, N, ldx,
+                     rpb, nrb > 1 ? workspace : out);
   REC_LAUNCH_CHECK();
+  if (nrb > 1) {
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div64(N, 256)), dim3(256), 0, st, workspace, nrb, N,
+                       out);
+    REC_LAUNCH_CHECK();
+  }
   return REC_OK;
 }
 

@@ -103,49 +103,76 @@ extern "C" int rec_emb_gather_f32(const float* table, int64_t V, int E, const in
 // ------------------------------------------------------------------------------------------------
 // K2+K3 fused forward.  Vector form: E = 4*LPR, LPR in {1,2,4,8,16}.
 // ------------------------------------------------------------------------------------------------
-template <int LPR>
+//
+// Latency is the enemy at batch 8192 (the whole gather is ~14 MB = ~2 us of HBM time), so the kernel has
+// exactly two dependent memory phases: (1) the workgroup's ids, read coalesced and parked in LDS as 32-bit
+// row numbers (-1 = out of range); (2) every row load of a lane issued back to back (NL = 16 float4 in
+// flight per lane).  An example is spread over LPR*SPLIT lanes: LPR lanes cover a row, SPLIT lane groups
+// share the example's F fields, so that 8192 x 26 lookups fill ~1024 waves instead of 512.
+template <int LPR, int SPLIT>
 __global__ __launch_bounds__(256) void emb_fm_fwd_vec_kernel(
     const float4* __restrict__ embed, const float* __restrict__ w, const float* __restrict__ bias, int64_t V,
     const int64_t* __restrict__ idx, int64_t B, int F, float* __restrict__ z, float* __restrict__ prob,
     float4* __restrict__ emb_out, float4* __restrict__ sumvec, int* oob) {
-  constexpr int UNR = 8;
-  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  int64_t b = t / LPR;
-  int c = (int)(t % LPR);
-  if (b >= B) return;  // whole lane groups leave together (256 % LPR == 0)
-  const int64_t* ids = idx + b * F;
+  constexpr int LPE = LPR * SPLIT;   // lanes per example
+  constexpr int EPW = 256 / LPE;     // examples per workgroup
+  constexpr int NL = 16;             // row loads in flight per lane
+  extern __shared__ int ids_lds[];   // [EPW * F]
+  const int tid = threadIdx.x;
+  const int64_t b0 = (int64_t)blockIdx.x * EPW;
+  const int n_ex = (B - b0 < EPW) ? (int)(B - b0) : EPW;
+  bool bad = false;
+  for (int i = tid; i < n_ex * F; i += 256) {
+    int64_t id = idx[b0 * F + i];
+    bool ok = (uint64_t)id < (uint64_t)V;
+    bad |= !ok;
+    ids_lds[i] = ok ? (int)id : -1;
+  }
+  if (bad && oob) *oob = 1;
+  __syncthreads();
+  const int e = tid / LPE, q = tid % LPE, c = q % LPR, s = q / LPR;
+  if (e >= n_ex) return;             // whole examples leave together, after the only barrier
+  const int64_t b = b0 + e;
+  const int FP = (F + SPLIT - 1) / SPLIT;
+  const int f_begin = s * FP;
+  const int f_end = (f_begin + FP < F) ? f_begin + FP : F;
+  const int* my_ids = ids_lds + e * F;
   float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 Q = make_float4(0.f, 0.f, 0.f, 0.f);
   float first = 0.f;
-  bool bad = false;
-  for (int f0 = 0; f0 < F; f0 += UNR) {
-    int64_t id[UNR];
-    float4 e[UNR];
-    float wv[UNR];
+  for (int f0 = f_begin; f0 < f_end; f0 += NL) {
+    int id[NL];
+    float4 ev[NL];
+    float wv[NL];
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) id[u] = (f0 + u < F) ? ids[f0 + u] : -1;
+    for (int u = 0; u < NL; ++u) id[u] = (f0 + u < f_end) ? my_ids[f0 + u] : -1;
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      bool ok = (uint64_t)id[u] < (uint64_t)V;
-      bad |= (f0 + u < F) && !ok;
-      e[u] = ok ? embed[id[u] * LPR + c] : make_float4(0.f, 0.f, 0.f, 0.f);
-      // the F first-order scalars of an example are spread over the LPR lanes of its group
-      wv[u] = (ok && ((f0 + u) % LPR) == c) ? w[id[u]] : 0.f;
+    for (int u = 0; u < NL; ++u) {
+      bool ok = id[u] >= 0;
+      ev[u] = ok ? embed[(int64_t)id[u] * LPR + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      // the first-order scalars of a lane group are spread over its LPR lanes
+      wv[u] = (ok && (u % LPR) == c) ? w[id[u]] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      S.x += e[u].x; S.y += e[u].y; S.z += e[u].z; S.w += e[u].w;
-      Q.x += e[u].x * e[u].x; Q.y += e[u].y * e[u].y; Q.z += e[u].z * e[u].z; Q.w += e[u].w * e[u].w;
+    for (int u = 0; u < NL; ++u) {
+      S.x += ev[u].x; S.y += ev[u].y; S.z += ev[u].z; S.w += ev[u].w;
+      Q.x += ev[u].x * ev[u].x; Q.y += ev[u].y * ev[u].y; Q.z += ev[u].z * ev[u].z; Q.w += ev[u].w * ev[u].w;
       first += wv[u];
-      if (emb_out && f0 + u < F) emb_out[(b * F + f0 + u) * LPR + c] = e[u];
+      if (emb_out && f0 + u < f_end) emb_out[(b * F + f0 + u) * LPR + c] = ev[u];
     }
   }
-  if (bad && oob) *oob = 1;
+#pragma unroll
+  for (int o = LPR; o < LPE; o <<= 1) {   // add the SPLIT partial sums of an example (lanes c, c+LPR, ...)
+    S.x += __shfl_xor(S.x, o, 64); S.y += __shfl_xor(S.y, o, 64);
+    S.z += __shfl_xor(S.z, o, 64); S.w += __shfl_xor(S.w, o, 64);
+    Q.x += __shfl_xor(Q.x, o, 64); Q.y += __shfl_xor(Q.y, o, 64);
+    Q.z += __shfl_xor(Q.z, o, 64); Q.w += __shfl_xor(Q.w, o, 64);
+  }
   float part = (S.x * S.x - Q.x) + (S.y * S.y - Q.y) + (S.z * S.z - Q.z) + (S.w * S.w - Q.w);
-  part = group_sum<LPR>(part);
-  first = group_sum<LPR>(first);
-  if (sumvec) sumvec[b * LPR + c] = S;
-  if (c == 0) {
+  part = group_sum<LPR>(part);            // over the row's lanes (every SPLIT group now holds the same S, Q)
+  first = group_sum<LPE>(first);
+  if (sumvec && s == 0) sumvec[b * LPR + c] = S;
+  if (q == 0) {
     float zz = bias[0] + first + 0.5f * part;
     if (z) z[b] = zz;
     if (prob) prob[b] = sigmoid_acc(zz);
@@ -200,10 +227,38 @@ __global__ __launch_bounds__(256) void emb_fm_fwd_gen_kernel(
   }
 }
 
-#define FWD_VEC(LPR)                                                                                     \
-  hipLaunchKernelGGL(emb_fm_fwd_vec_kernel<LPR>, dim3((unsigned)ceil_div64(B * LPR, 256)), dim3(256), 0, \
-                     as_stream(stream), (const float4*)embed, w, bias, V, idx, B, F, z, prob,             \
-                     (float4*)emb_out, (float4*)sumvec, oob_flag)
+template <int LPR, int SPLIT>
+static void launch_fwd_vec(const float* embed, const float* w, const float* bias, int64_t V, const int64_t* idx,
+                           int64_t B, int F, float* z, float* prob, float* emb_out, float* sumvec, int* oob_flag,
+                           hipStream_t st) {
+  constexpr int EPW = 256 / (LPR * SPLIT);
+  size_t lds = sizeof(int) * (size_t)EPW * (size_t)F;
+  hipLaunchKernelGGL((emb_fm_fwd_vec_kernel<LPR, SPLIT>), dim3((unsigned)ceil_div64(B, EPW)), dim3(256), lds, st,
+                     (const float4*)embed, w, bias, V, idx, B, F, z, prob, (float4*)emb_out, (float4*)sumvec,
+                     oob_flag);
+}
+
+// lanes of an example = LPR * SPLIT: split the fields of an example over 2 or 4 lane groups when that is
+// needed to keep <= 16 row loads per lane or to fill the chip (>= ~1024 waves)
+template <int LPR>
+static bool dispatch_fwd_vec(const float* embed, const float* w, const float* bias, int64_t V, const int64_t* idx,
+                             int64_t B, int F, float* z, float* prob, float* emb_out, float* sumvec, int* oob_flag,
+                             hipStream_t st) {
+  int split = 1;
+  while (split < 4 && LPR * split * 2 <= 64 &&
+         ((F + split - 1) / split > 16 || B * LPR * split < 1024 * 64) && (F + split - 1) / split > 1)
+    split *= 2;
+  if (sizeof(int) * (size_t)(256 / (LPR * split)) * (size_t)F > 60 * 1024) return false;
+  if (split == 1) launch_fwd_vec<LPR, 1>(embed, w, bias, V, idx, B, F, z, prob, emb_out, sumvec, oob_flag, st);
+  else if (split == 2) launch_fwd_vec<LPR, 2>(embed, w, bias, V, idx, B, F, z, prob, emb_out, sumvec, oob_flag, st);
+  else launch_fwd_vec<LPR, (LPR * 4 <= 64 ? 4 : 2)>(embed, w, bias, V, idx, B, F, z, prob, emb_out, sumvec, oob_flag, st);
+  return true;
+}
+
+#define FWD_VEC(LPR)                                                                                        \
+  if (!dispatch_fwd_vec<LPR>(embed, w, bias, V, idx, B, F, z, prob, emb_out, sumvec, oob_flag,              \
+                             as_stream(stream)))                                                            \
+    return REC_E_UNSUPPORTED
 #define FWD_GEN(GW, NACC)                                                                                      \
   hipLaunchKernelGGL((emb_fm_fwd_gen_kernel<GW, NACC>), dim3((unsigned)ceil_div64(B * GW, 256)), dim3(256), 0, \
                      as_stream(stream), embed, w, bias, V, E, idx, B, F, z, prob, emb_out, sumvec, oob_flag)

@@ -182,7 +182,8 @@ def colsum(X, out=None):
     M, N = X.shape
     if out is None:
         out = torch.empty(N, dtype=torch.float32, device=X.device)
-    check(lib.rec_colsum_f32(_ptr(X), M, N, X.stride(0), _ptr(out), _stream()), "rec_colsum_f32")
+    ws = torch.empty(lib.rec_colsum_workspace_bytes(M, N) // 4, dtype=torch.float32, device=X.device)
+    check(lib.rec_colsum_f32(_ptr(X), M, N, X.stride(0), _ptr(out), _ptr(ws), _stream()), "rec_colsum_f32")
     return out
 
 

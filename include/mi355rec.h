@@ -114,8 +114,10 @@ int rec_crossnet_mat_bwd_elem_f32(const float* g, const float* x0, const float* 
 int rec_act_fwd_f32(int act, const float* x, const float* x2, float* y, int64_t n, void* stream);
 /* dpre = dpost * act'(post)   (in place allowed) */
 int rec_act_bwd_f32(int act, const float* post, const float* dpost, float* dpre, int64_t n, void* stream);
-/* out[j] = sum_i X[i,j]  (bias gradients), deterministic */
-int rec_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx, float* out, void* stream);
+/* out[j] = sum_i X[i,j]  (bias gradients), deterministic two-stage sum; workspace of
+ * rec_colsum_workspace_bytes(M,N) bytes. */
+size_t rec_colsum_workspace_bytes(int64_t M, int64_t N);
+int rec_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx, float* out, float* workspace, void* stream);
 /* y = a*x + b*y over n elements */
 int rec_axpby_f32(float a, const float* x, float b, float* y, int64_t n, void* stream);
 /* dst[r, c0:c0+w] = src[r, 0:w]   (concat / split along the feature axis) */
