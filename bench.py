@@ -161,8 +161,8 @@ def main():
     def launch_gather(n):
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         for _ in range(n):
-            check(lib.rec_emb_fm_fwd_f32(vp(emb), vp(w), vp(bias), V, E, vp(X), B, F, vp(zbuf), None, None, None,
-                                         None, st), "rec_emb_fm_fwd_f32")
+            check(lib.rec_emb_fm_fwd_f32(vp(emb), emb.stride(0), vp(w), w.stride(0), vp(bias), V, E, vp(X), B, F,
+                                         vp(zbuf), None, None, None, None, st), "rec_emb_fm_fwd_f32")
 
     launch_gather(10)
     torch.cuda.synchronize()
@@ -178,7 +178,7 @@ def main():
     torch.cuda.synchronize()
     kern_us = ev0.elapsed_time(ev1) * 1e3 / reps
     achieved = algo_bytes / (kern_us * 1e-6) / 1e9
-    roofline = {"bound": "hbm", "kernel": "emb_fm_fwd_vec_kernel<4> (gather + FM, no row write-back)",
+    roofline = {"bound": "hbm", "kernel": "emb_fm_fwd_vec_kernel<8,2,fused> (gather + FM over fused 128-B rows, no row write-back)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None, "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": kern_us,
                 "timing": "HIP events around %d back-to-back launches on the launch stream" % reps}

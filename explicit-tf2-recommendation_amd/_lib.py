@@ -16,9 +16,9 @@ p, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
     "rec_version": (i32, []),
     "rec_index_pack_i64": (i32, [p, i32, i64, p, i64, i64, p]),
-    "rec_emb_gather_f32": (i32, [p, i64, i32, p, i64, p, p, p]),
-    "rec_emb_fm_fwd_f32": (i32, [p, p, p, i64, i32, p, i64, i32, p, p, p, p, p, p]),
-    "rec_emb_fm_bwd_vals_f32": (i32, [p, i64, i32, p, i64, i32, p, p, p, p, p, p]),
+    "rec_emb_gather_f32": (i32, [p, i64, i32, i64, p, i64, p, p, p]),
+    "rec_emb_fm_fwd_f32": (i32, [p, i64, p, i64, p, i64, i32, p, i64, i32, p, p, p, p, p, p]),
+    "rec_emb_fm_bwd_vals_f32": (i32, [p, i64, i64, i32, p, i64, i32, p, p, p, p, p, p]),
     "rec_dedup_workspace_bytes": (sz, [i64]),
     "rec_dedup_plan_i64": (i32, [p, i64, i64, p, p, p, p, p, sz, p]),
     "rec_segment_sum_f32": (i32, [p, i32, p, p, i64, i32, p, p]),
@@ -37,8 +37,8 @@ SIGNATURES = {
     "rec_cosine_bwd_f32": (i32, [p, p, i64, i32, p, p, p, p]),
     "rec_bce_fwd_bwd_f32": (i32, [p, p, i64, p, p, p, p]),
     "rec_adam_dense_f32": (i32, [p, p, p, p, i64, i64, f32, f32, f32, f32, p]),
-    "rec_adam_sparse_keras_f32": (i32, [p, p, p, i64, i32, p, p, p, i64, p, i64, f32, f32, f32, f32, p]),
-    "rec_adam_rows_f32": (i32, [p, p, p, i64, i32, p, p, p, i64, i64, f32, f32, f32, f32, p]),
+    "rec_adam_sparse_keras_f32": (i32, [p, i64, p, p, i64, i32, p, p, p, i64, p, i64, f32, f32, f32, f32, p]),
+    "rec_adam_rows_f32": (i32, [p, i64, p, p, i64, i32, p, p, p, i64, i64, f32, f32, f32, f32, p]),
     "rec_shard_bucketize_workspace_bytes": (sz, [i64, i32]),
     "rec_shard_bucketize_i64": (i32, [p, i64, i64, i32, p, p, p, p, p, sz, p]),
     "rec_permute_rows_f32": (i32, [p, p, i64, i32, i32, p, p]),

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ var
 // touched rows: new (var, m, v) computed from the ORIGINAL state into `side` [cap, 3, E]
 __global__ __launch_bounds__(256) void adam_rows_side_kernel(const float* __restrict__ var, const float* __restrict__ m,
                                                              const float* __restrict__ v, int64_t V, int E,
-                                                             const int64_t* __restrict__ ids,
+                                                             int64_t ld, const int64_t* __restrict__ ids,
                                                              const float* __restrict__ g, const int64_t* n_uniq,
                                                              int64_t cap, float* __restrict__ side, float lr_t,
                                                              float b1, float b2, float eps) {
@@ -347,19 +347,23 @@ __global__ __launch_bounds__(256) void adam_rows_side_kernel(const float* __rest
   float gg = g[t];
   float mm = m[id * E + d] * b1 + gg * (1.f - b1);
   float vv = v[id * E + d] * b2 + gg * gg * (1.f - b2);
-  side[(u * 3 + 0) * E + d] = var[id * E + d] - lr_t * mm / (sqrtf(vv) + eps);
+  side[(u * 3 + 0) * E + d] = var[id * ld + d] - lr_t * mm / (sqrtf(vv) + eps);
   side[(u * 3 + 1) * E + d] = mm;
   side[(u * 3 + 2) * E + d] = vv;
 }
 
-// all rows: the untouched-row form of the dense sweep (streaming, float4 when possible)
-__global__ __launch_bounds__(256) void adam_sweep_vec_kernel(float4* __restrict__ var, float4* __restrict__ m,
-                                                             float4* __restrict__ v, int64_t n4, float lr_t, float b1,
-                                                             float b2, float eps) {
+// all rows: the untouched-row form of the dense sweep (streaming; float4 when E and ld allow).  var has row
+// stride ld (fused-table layout), m and v are dense [V,E].
+__global__ __launch_bounds__(256) void adam_sweep_vec_kernel(float* __restrict__ var, int64_t ld, int lpr,
+                                                             float4* __restrict__ m, float4* __restrict__ v, int64_t n4,
+                                                             float lr_t, float b1, float b2, float eps) {
   int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * 256;
   for (; t < n4; t += stride) {
-    float4 mm = m[t], vv = v[t], x = var[t];
+    int64_t r = t / lpr;
+    int c = (int)(t - r * lpr);
+    float4* xp = reinterpret_cast<float4*>(var + r * ld + 4 * c);
+    float4 mm = m[t], vv = v[t], x = *xp;
     mm.x *= b1; mm.y *= b1; mm.z *= b1; mm.w *= b1;
     vv.x *= b2; vv.y *= b2; vv.z *= b2; vv.w *= b2;
     x.x -= lr_t * mm.x / (sqrtf(vv.x) + eps);
@@ -368,25 +372,27 @@ __global__ __launch_bounds__(256) void adam_sweep_vec_kernel(float4* __restrict_
     x.w -= lr_t * mm.w / (sqrtf(vv.w) + eps);
     m[t] = mm;
     v[t] = vv;
-    var[t] = x;
+    *xp = x;
   }
 }
 
-__global__ __launch_bounds__(256) void adam_sweep_scalar_kernel(float* __restrict__ var, float* __restrict__ m,
-                                                                float* __restrict__ v, int64_t n, float lr_t, float b1,
-                                                                float b2, float eps) {
+__global__ __launch_bounds__(256) void adam_sweep_scalar_kernel(float* __restrict__ var, int64_t ld, int E,
+                                                                float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                                float lr_t, float b1, float b2, float eps) {
   int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * 256;
   for (; t < n; t += stride) {
+    int64_t r = t / E;
+    int d = (int)(t - r * E);
     float mm = m[t] * b1, vv = v[t] * b2;
     m[t] = mm;
     v[t] = vv;
-    var[t] = var[t] - lr_t * mm / (sqrtf(vv) + eps);
+    var[r * ld + d] = var[r * ld + d] - lr_t * mm / (sqrtf(vv) + eps);
   }
 }
 
 __global__ __launch_bounds__(256) void adam_rows_patch_kernel(float* __restrict__ var, float* __restrict__ m,
-                                                              float* __restrict__ v, int64_t V, int E,
+                                                              float* __restrict__ v, int64_t V, int E, int64_t ld,
                                                               const int64_t* __restrict__ ids, const int64_t* n_uniq,
                                                               int64_t cap, const float* __restrict__ side) {
   int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -396,13 +402,13 @@ __global__ __launch_bounds__(256) void adam_rows_patch_kernel(float* __restrict_
   if (u >= *n_uniq) return;
   int64_t id = ids[u];
   if ((uint64_t)id >= (uint64_t)V) return;
-  var[id * E + d] = side[(u * 3 + 0) * E + d];
+  var[id * ld + d] = side[(u * 3 + 0) * E + d];
   m[id * E + d] = side[(u * 3 + 1) * E + d];
   v[id * E + d] = side[(u * 3 + 2) * E + d];
 }
 
 __global__ __launch_bounds__(256) void adam_rows_lazy_kernel(float* __restrict__ var, float* __restrict__ m,
-                                                             float* __restrict__ v, int64_t V, int E,
+                                                             float* __restrict__ v, int64_t V, int E, int64_t ld,
                                                              const int64_t* __restrict__ ids, const float* __restrict__ g,
                                                              const int64_t* n_uniq, int64_t cap, float lr_t, float b1,
                                                              float b2, float eps) {
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(256) void adam_rows_lazy_kernel(float* __restrict__
   float vv = v[id * E + d] * b2 + gg * gg * (1.f - b2);
   m[id * E + d] = mm;
   v[id * E + d] = vv;
-  var[id * E + d] = var[id * E + d] - lr_t * mm / (sqrtf(vv) + eps);
+  var[id * ld + d] = var[id * ld + d] - lr_t * mm / (sqrtf(vv) + eps);
 }
 
 inline float adam_lr_t(float lr, float b1, float b2, int64_t t) {
@@ -609,47 +615,51 @@ extern "C" int rec_adam_dense_f32(float* var, float* m, float* v, const float* g
   return REC_OK;
 }
 
-extern "C" int rec_adam_sparse_keras_f32(float* var, float* m, float* v, int64_t V, int E, const int64_t* uniq_ids,
-                                         const float* g_rows, const int64_t* n_uniq, int64_t cap, float* side,
-                                         int64_t t, float lr, float b1, float b2, float eps, void* stream) {
-  if (!var || !m || !v || !uniq_ids || !g_rows || !n_uniq || !side || V <= 0 || E <= 0 || cap < 0 || t < 1)
+extern "C" int rec_adam_sparse_keras_f32(float* var, int64_t ld, float* m, float* v, int64_t V, int E,
+                                         const int64_t* uniq_ids, const float* g_rows, const int64_t* n_uniq,
+                                         int64_t cap, float* side, int64_t t, float lr, float b1, float b2, float eps,
+                                         void* stream) {
+  if (!var || !m || !v || !uniq_ids || !g_rows || !n_uniq || !side || V <= 0 || E <= 0 || ld < E || cap < 0 || t < 1)
     return REC_E_ARG;
   hipStream_t st = as_stream(stream);
   float lr_t = adam_lr_t(lr, b1, b2, t);
   if (cap > 0) {
     hipLaunchKernelGGL(adam_rows_side_kernel, dim3((unsigned)ceil_div64(cap * E, 256)), dim3(256), 0, st, var, m, v, V,
-                       E, uniq_ids, g_rows, n_uniq, cap, side, lr_t, b1, b2, eps);
+                       E, ld, uniq_ids, g_rows, n_uniq, cap, side, lr_t, b1, b2, eps);
     REC_LAUNCH_CHECK();
   }
   int64_t n = V * E;
-  if (n % 4 == 0) {
+  bool vec = E % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(var) & 15) == 0 &&
+             (reinterpret_cast<uintptr_t>(m) & 15) == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0;
+  if (vec) {
     int64_t n4 = n / 4;
     int64_t blocks = ceil_div64(n4, 256);
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(adam_sweep_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (float4*)var, (float4*)m,
+    hipLaunchKernelGGL(adam_sweep_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, st, var, ld, E / 4, (float4*)m,
                        (float4*)v, n4, lr_t, b1, b2, eps);
   } else {
     int64_t blocks = ceil_div64(n, 256);
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(adam_sweep_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, st, var, m, v, n, lr_t, b1, b2,
-                       eps);
+    hipLaunchKernelGGL(adam_sweep_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, st, var, ld, E, m, v, n, lr_t,
+                       b1, b2, eps);
   }
   REC_LAUNCH_CHECK();
   if (cap > 0) {
     hipLaunchKernelGGL(adam_rows_patch_kernel, dim3((unsigned)ceil_div64(cap * E, 256)), dim3(256), 0, st, var, m, v, V,
-                       E, uniq_ids, n_uniq, cap, side);
+                       E, ld, uniq_ids, n_uniq, cap, side);
     REC_LAUNCH_CHECK();
   }
   return REC_OK;
 }
 
-extern "C" int rec_adam_rows_f32(float* var, float* m, float* v, int64_t V, int E, const int64_t* uniq_ids,
+extern "C" int rec_adam_rows_f32(float* var, int64_t ld, float* m, float* v, int64_t V, int E, const int64_t* uniq_ids,
                                  const float* g_rows, const int64_t* n_uniq, int64_t cap, int64_t t, float lr, float b1,
                                  float b2, float eps, void* stream) {
-  if (!var || !m || !v || !uniq_ids || !g_rows || !n_uniq || V <= 0 || E <= 0 || cap < 0 || t < 1) return REC_E_ARG;
+  if (!var || !m || !v || !uniq_ids || !g_rows || !n_uniq || V <= 0 || E <= 0 || ld < E || cap < 0 || t < 1)
+    return REC_E_ARG;
   if (cap == 0) return REC_OK;
   hipLaunchKernelGGL(adam_rows_lazy_kernel, dim3((unsigned)ceil_div64(cap * E, 256)), dim3(256), 0, as_stream(stream),
-                     var, m, v, V, E, uniq_ids, g_rows, n_uniq, cap, adam_lr_t(lr, b1, b2, t), b1, b2, eps);
+                     var, m, v, V, E, ld, uniq_ids, g_rows, n_uniq, cap, adam_lr_t(lr, b1, b2, t), b1, b2, eps);
   REC_LAUNCH_CHECK();
   return REC_OK;
 }

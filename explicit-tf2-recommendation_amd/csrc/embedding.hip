@@ -4,10 +4,13 @@
 //   K3  FM sum-square trick   2.FM/CustomLayers.py:149-155  (fused with K2)
 //   K4  per-lookup gradient values of the FM part (IndexedSlices values), 2.FM/ModelManager.py:176-177
 //
-// HBM-bound gathers: a row of E fp32 is read by LPR = E/4 adjacent lanes as float4 (one 64-B request for
-// E=16), one lane group per example, the F row loads of an example issued back to back so that every
-// lane keeps >= 8 independent 16-B loads in flight; sum / sum-of-squares accumulate in registers and the
-// E-reduction is a wave shuffle butterfly inside the lane group.
+// What bounds these kernels on MI355X (measured, scripts/exp/gather_bench*.hip): a random row read costs one
+// 128-B line request whatever the row size (32, 64 and 128-B rows all run at ~50 G lookups/s chip-wide; 256-B
+// rows and "64-B row + separate 4-B scalar" at half that).  So (1) tables carry a row stride (`ld`) and the
+// FM layers keep `embed` and `w` of one id in ONE 128-B line (fused layout: row = [embed(E) | w | pad],
+// ld = next_pow2(E+1) >= 16) -- the first-order weight then rides along for free; (2) a kernel has exactly two
+// dependent memory phases (ids, then every row load of a lane issued back to back), because at batch 8192 the
+// whole gather is ~4 us and any extra dependent round trip shows.
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -47,10 +50,10 @@ extern "C" int rec_index_pack_i64(const int64_t* const* cols_host, int F, int64_
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2  plain gather
+// K2  plain gather (table row stride ld, output dense [n,E])
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gather_vec4_kernel(const float4* __restrict__ table, int64_t V, int lpr,
-                                                          const int64_t* __restrict__ idx, int64_t n,
+__global__ __launch_bounds__(256) void gather_vec4_kernel(const float* __restrict__ table, int64_t V, int lpr,
+                                                          int64_t ld, const int64_t* __restrict__ idx, int64_t n,
                                                           float4* __restrict__ out, int* oob) {
   int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n * lpr) return;
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(256) void gather_vec4_kernel(const float4* __restri
   int64_t id = idx[r];
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if ((uint64_t)id < (uint64_t)V) {
-    v = table[id * lpr + c];
+    v = *reinterpret_cast<const float4*>(table + id * ld + 4 * c);
   } else if (oob) {
     *oob = 1;
   }
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void gather_vec4_kernel(const float4* __restri
 }
 
 __global__ __launch_bounds__(256) void gather_scalar_kernel(const float* __restrict__ table, int64_t V, int E,
-                                                            const int64_t* __restrict__ idx, int64_t n,
+                                                            int64_t ld, const int64_t* __restrict__ idx, int64_t n,
                                                             float* __restrict__ out, int* oob) {
   int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n * E) return;
@@ -76,44 +79,48 @@ __global__ __launch_bounds__(256) void gather_scalar_kernel(const float* __restr
   int64_t id = idx[r];
   float v = 0.f;
   if ((uint64_t)id < (uint64_t)V) {
-    v = table[id * E + d];
+    v = table[id * ld + d];
   } else if (oob) {
     *oob = 1;
   }
   out[t] = v;
 }
 
-extern "C" int rec_emb_gather_f32(const float* table, int64_t V, int E, const int64_t* idx, int64_t n,
+static inline bool vec4_ok(const void* p, int E, int64_t ld) {
+  return E % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+}
+
+extern "C" int rec_emb_gather_f32(const float* table, int64_t V, int E, int64_t ld, const int64_t* idx, int64_t n,
                                   float* out, int* oob_flag, void* stream) {
-  if (V <= 0 || E <= 0 || n < 0) return REC_E_ARG;
+  if (V <= 0 || E <= 0 || ld < E || n < 0) return REC_E_ARG;
   if (n == 0) return REC_OK;
   if (!table || !idx || !out) return REC_E_ARG;
-  if (E % 4 == 0) {
+  if (vec4_ok(table, E, ld) && vec4_ok(out, E, E)) {
     int lpr = E / 4;
     hipLaunchKernelGGL(gather_vec4_kernel, dim3((unsigned)ceil_div64(n * lpr, 256)), dim3(256), 0,
-                       as_stream(stream), (const float4*)table, V, lpr, idx, n, (float4*)out, oob_flag);
+                       as_stream(stream), table, V, lpr, ld, idx, n, (float4*)out, oob_flag);
   } else {
     hipLaunchKernelGGL(gather_scalar_kernel, dim3((unsigned)ceil_div64(n * E, 256)), dim3(256), 0,
-                       as_stream(stream), table, V, E, idx, n, out, oob_flag);
+                       as_stream(stream), table, V, E, ld, idx, n, out, oob_flag);
   }
   REC_LAUNCH_CHECK();
   return REC_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2+K3 fused forward.  Vector form: E = 4*LPR, LPR in {1,2,4,8,16}.
+// K2+K3 fused forward, vector form.
+//   LPR   lanes (float4 each) that cover one table row of ld = 4*LPR floats
+//   NE    = E/4 leading lanes of a row that carry embedding dims
+//   fused : w[id] is float NE*4 of the same row (lane NE, component x); else w is a separate table
+//   SPLIT lane groups share the F fields of one example (fills the chip at batch 8192)
+// ids of the workgroup are read coalesced and parked in LDS as 32-bit row numbers (-1 = out of range).
 // ------------------------------------------------------------------------------------------------
-//
-// Latency is the enemy at batch 8192 (the whole gather is ~14 MB = ~2 us of HBM time), so the kernel has
-// exactly two dependent memory phases: (1) the workgroup's ids, read coalesced and parked in LDS as 32-bit
-// row numbers (-1 = out of range); (2) every row load of a lane issued back to back (NL = 16 float4 in
-// flight per lane).  An example is spread over LPR*SPLIT lanes: LPR lanes cover a row, SPLIT lane groups
-// share the example's F fields, so that 8192 x 26 lookups fill ~1024 waves instead of 512.
-template <int LPR, int SPLIT>
+template <int LPR, int SPLIT, bool FUSED>
 __global__ __launch_bounds__(256) void emb_fm_fwd_vec_kernel(
-    const float4* __restrict__ embed, const float* __restrict__ w, const float* __restrict__ bias, int64_t V,
-    const int64_t* __restrict__ idx, int64_t B, int F, float* __restrict__ z, float* __restrict__ prob,
-    float4* __restrict__ emb_out, float4* __restrict__ sumvec, int* oob) {
+    const float* __restrict__ embed, int64_t ld_e, const float* __restrict__ w, int64_t ld_w,
+    const float* __restrict__ bias, int64_t V, int NE, const int64_t* __restrict__ idx, int64_t B, int F,
+    float* __restrict__ z, float* __restrict__ prob, float4* __restrict__ emb_out, float4* __restrict__ sumvec,
+    int* oob) {
   constexpr int LPE = LPR * SPLIT;   // lanes per example
   constexpr int EPW = 256 / LPE;     // examples per workgroup
   constexpr int NL = 16;             // row loads in flight per lane
@@ -137,6 +144,7 @@ __global__ __launch_bounds__(256) void emb_fm_fwd_vec_kernel(
   const int f_begin = s * FP;
   const int f_end = (f_begin + FP < F) ? f_begin + FP : F;
   const int* my_ids = ids_lds + e * F;
+  const bool emb_lane = c < NE;
   float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 Q = make_float4(0.f, 0.f, 0.f, 0.f);
   float first = 0.f;
@@ -149,16 +157,26 @@ __global__ __launch_bounds__(256) void emb_fm_fwd_vec_kernel(
 #pragma unroll
     for (int u = 0; u < NL; ++u) {
       bool ok = id[u] >= 0;
-      ev[u] = ok ? embed[(int64_t)id[u] * LPR + c] : make_float4(0.f, 0.f, 0.f, 0.f);
-      // the first-order scalars of a lane group are spread over its LPR lanes
-      wv[u] = (ok && (u % LPR) == c) ? w[id[u]] : 0.f;
+      ev[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      wv[u] = 0.f;
+      if (FUSED) {
+        // every lane of the row group reads its 16 B of the line; lane NE holds w in .x
+        if (ok && c <= NE) ev[u] = *reinterpret_cast<const float4*>(embed + (int64_t)id[u] * ld_e + 4 * c);
+      } else {
+        if (ok && emb_lane) ev[u] = *reinterpret_cast<const float4*>(embed + (int64_t)id[u] * ld_e + 4 * c);
+        if (ok && (u % LPR) == c) wv[u] = w[(int64_t)id[u] * ld_w];
+      }
     }
 #pragma unroll
     for (int u = 0; u < NL; ++u) {
-      S.x += ev[u].x; S.y += ev[u].y; S.z += ev[u].z; S.w += ev[u].w;
-      Q.x += ev[u].x * ev[u].x; Q.y += ev[u].y * ev[u].y; Q.z += ev[u].z * ev[u].z; Q.w += ev[u].w * ev[u].w;
+      if (FUSED && c == NE) {
+        first += ev[u].x;
+      } else if (emb_lane) {
+        S.x += ev[u].x; S.y += ev[u].y; S.z += ev[u].z; S.w += ev[u].w;
+        Q.x += ev[u].x * ev[u].x; Q.y += ev[u].y * ev[u].y; Q.z += ev[u].z * ev[u].z; Q.w += ev[u].w * ev[u].w;
+        if (emb_out && f0 + u < f_end) emb_out[(b * F + f0 + u) * NE + c] = ev[u];
+      }
       first += wv[u];
-      if (emb_out && f0 + u < f_end) emb_out[(b * F + f0 + u) * LPR + c] = ev[u];
     }
   }
 #pragma unroll
@@ -169,9 +187,9 @@ __global__ __launch_bounds__(256) void emb_fm_fwd_vec_kernel(
     Q.z += __shfl_xor(Q.z, o, 64); Q.w += __shfl_xor(Q.w, o, 64);
   }
   float part = (S.x * S.x - Q.x) + (S.y * S.y - Q.y) + (S.z * S.z - Q.z) + (S.w * S.w - Q.w);
-  part = group_sum<LPR>(part);            // over the row's lanes (every SPLIT group now holds the same S, Q)
+  part = group_sum<LPR>(part);            // over the row's lanes (non-embedding lanes contribute 0)
   first = group_sum<LPE>(first);
-  if (sumvec && s == 0) sumvec[b * LPR + c] = S;
+  if (sumvec && s == 0 && emb_lane) sumvec[b * NE + c] = S;
   if (q == 0) {
     float zz = bias[0] + first + 0.5f * part;
     if (z) z[b] = zz;
@@ -179,13 +197,14 @@ __global__ __launch_bounds__(256) void emb_fm_fwd_vec_kernel(
   }
 }
 
-// Generic form: any E <= 4*64; a group of GW lanes (power of two >= min(E,64)) per example, lane c owns
-// dims c, c+GW, ...
+// Generic form: any E <= 4*64 and any strides; a group of GW lanes (power of two >= min(E,64)) per example,
+// lane c owns dims c, c+GW, ...
 template <int GW, int NACC>
 __global__ __launch_bounds__(256) void emb_fm_fwd_gen_kernel(
-    const float* __restrict__ embed, const float* __restrict__ w, const float* __restrict__ bias, int64_t V,
-    int E, const int64_t* __restrict__ idx, int64_t B, int F, float* __restrict__ z, float* __restrict__ prob,
-    float* __restrict__ emb_out, float* __restrict__ sumvec, int* oob) {
+    const float* __restrict__ embed, int64_t ld_e, const float* __restrict__ w, int64_t ld_w,
+    const float* __restrict__ bias, int64_t V, int E, const int64_t* __restrict__ idx, int64_t B, int F,
+    float* __restrict__ z, float* __restrict__ prob, float* __restrict__ emb_out, float* __restrict__ sumvec,
+    int* oob) {
   int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   int64_t b = t / GW;
   int c = (int)(t % GW);
@@ -203,12 +222,12 @@ __global__ __launch_bounds__(256) void emb_fm_fwd_gen_kernel(
 #pragma unroll
     for (int a = 0; a < NACC; ++a) {
       int d = c + a * GW;
-      float e = (ok && d < E) ? embed[id * E + d] : 0.f;
+      float e = (ok && d < E) ? embed[id * ld_e + d] : 0.f;
       S[a] += e;
       Q[a] += e * e;
       if (emb_out && d < E) emb_out[(b * F + f) * E + d] = e;
     }
-    if (ok && (f % GW) == c) first += w[id];
+    if (ok && (f % GW) == c) first += w[id * ld_w];
   }
   if (bad && oob) *oob = 1;
   float part = 0.f;
@@ -227,65 +246,85 @@ __global__ __launch_bounds__(256) void emb_fm_fwd_gen_kernel(
   }
 }
 
-template <int LPR, int SPLIT>
-static void launch_fwd_vec(const float* embed, const float* w, const float* bias, int64_t V, const int64_t* idx,
-                           int64_t B, int F, float* z, float* prob, float* emb_out, float* sumvec, int* oob_flag,
-                           hipStream_t st) {
+namespace {
+
+struct FwdArgs {
+  const float* embed; int64_t ld_e; const float* w; int64_t ld_w; const float* bias; int64_t V; int E;
+  const int64_t* idx; int64_t B; int F; float* z; float* prob; float* emb_out; float* sumvec; int* oob;
+  hipStream_t st;
+};
+
+template <int LPR, int SPLIT, bool FUSED>
+void launch_vec(const FwdArgs& a) {
   constexpr int EPW = 256 / (LPR * SPLIT);
-  size_t lds = sizeof(int) * (size_t)EPW * (size_t)F;
-  hipLaunchKernelGGL((emb_fm_fwd_vec_kernel<LPR, SPLIT>), dim3((unsigned)ceil_div64(B, EPW)), dim3(256), lds, st,
-                     (const float4*)embed, w, bias, V, idx, B, F, z, prob, (float4*)emb_out, (float4*)sumvec,
-                     oob_flag);
+  size_t lds = sizeof(int) * (size_t)EPW * (size_t)a.F;
+  hipLaunchKernelGGL((emb_fm_fwd_vec_kernel<LPR, SPLIT, FUSED>), dim3((unsigned)ceil_div64(a.B, EPW)), dim3(256), lds,
+                     a.st, a.embed, a.ld_e, a.w, a.ld_w, a.bias, a.V, a.E / 4, a.idx, a.B, a.F, a.z, a.prob,
+                     (float4*)a.emb_out, (float4*)a.sumvec, a.oob);
 }
 
-// lanes of an example = LPR * SPLIT: split the fields of an example over 2 or 4 lane groups when that is
-// needed to keep <= 16 row loads per lane or to fill the chip (>= ~1024 waves)
-template <int LPR>
-static bool dispatch_fwd_vec(const float* embed, const float* w, const float* bias, int64_t V, const int64_t* idx,
-                             int64_t B, int F, float* z, float* prob, float* emb_out, float* sumvec, int* oob_flag,
-                             hipStream_t st) {
+// lanes of an example = LPR * SPLIT: split the fields of an example over 2 or 4 lane groups when that is needed
+// to keep <= 16 row loads per lane or to fill the chip (>= ~1024 waves)
+template <int LPR, bool FUSED>
+bool dispatch_vec(const FwdArgs& a) {
   int split = 1;
-  while (split < 4 && LPR * split * 2 <= 64 &&
-         ((F + split - 1) / split > 16 || B * LPR * split < 1024 * 64) && (F + split - 1) / split > 1)
+  while (split < 4 && LPR * split * 2 <= 64 && (a.F + split - 1) / split > 1 &&
+         ((a.F + split - 1) / split > 16 || a.B * LPR * split < 1024 * 64))
     split *= 2;
-  if (sizeof(int) * (size_t)(256 / (LPR * split)) * (size_t)F > 60 * 1024) return false;
-  if (split == 1) launch_fwd_vec<LPR, 1>(embed, w, bias, V, idx, B, F, z, prob, emb_out, sumvec, oob_flag, st);
-  else if (split == 2) launch_fwd_vec<LPR, 2>(embed, w, bias, V, idx, B, F, z, prob, emb_out, sumvec, oob_flag, st);
-  else launch_fwd_vec<LPR, (LPR * 4 <= 64 ? 4 : 2)>(embed, w, bias, V, idx, B, F, z, prob, emb_out, sumvec, oob_flag, st);
+  if (sizeof(int) * (size_t)(256 / (LPR * split)) * (size_t)a.F > 60 * 1024) return false;
+  if (split == 1) launch_vec<LPR, 1, FUSED>(a);
+  else if (split == 2) launch_vec<LPR, 2, FUSED>(a);
+  else launch_vec<LPR, (LPR * 4 <= 64 ? 4 : 2), FUSED>(a);
   return true;
 }
 
-#define FWD_VEC(LPR)                                                                                        \
-  if (!dispatch_fwd_vec<LPR>(embed, w, bias, V, idx, B, F, z, prob, emb_out, sumvec, oob_flag,              \
-                             as_stream(stream)))                                                            \
-    return REC_E_UNSUPPORTED
+template <bool FUSED>
+bool dispatch_lpr(const FwdArgs& a, int lpr) {
+  switch (lpr) {
+    case 1: return dispatch_vec<1, FUSED>(a);
+    case 2: return dispatch_vec<2, FUSED>(a);
+    case 4: return dispatch_vec<4, FUSED>(a);
+    case 8: return dispatch_vec<8, FUSED>(a);
+    case 16: return dispatch_vec<16, FUSED>(a);
+    default: return false;
+  }
+}
+
+}  // namespace
+
 #define FWD_GEN(GW, NACC)                                                                                      \
   hipLaunchKernelGGL((emb_fm_fwd_gen_kernel<GW, NACC>), dim3((unsigned)ceil_div64(B * GW, 256)), dim3(256), 0, \
-                     as_stream(stream), embed, w, bias, V, E, idx, B, F, z, prob, emb_out, sumvec, oob_flag)
+                     as_stream(stream), embed, ld_e, w, ld_w, bias, V, E, idx, B, F, z, prob, emb_out, sumvec,  \
+                     oob_flag)
 
-extern "C" int rec_emb_fm_fwd_f32(const float* embed, const float* w, const float* bias, int64_t V, int E,
-                                  const int64_t* idx, int64_t B, int F, float* z, float* prob, float* emb_out,
-                                  float* sumvec, int* oob_flag, void* stream) {
-  if (V <= 0 || E <= 0 || B < 0 || F <= 0) return REC_E_ARG;
+extern "C" int rec_emb_fm_fwd_f32(const float* embed, int64_t ld_e, const float* w, int64_t ld_w, const float* bias,
+                                  int64_t V, int E, const int64_t* idx, int64_t B, int F, float* z, float* prob,
+                                  float* emb_out, float* sumvec, int* oob_flag, void* stream) {
+  if (V <= 0 || E <= 0 || B < 0 || F <= 0 || ld_e < E || ld_w < 1) return REC_E_ARG;
   if (E > 256) return REC_E_UNSUPPORTED;
   if (B == 0) return REC_OK;
   if (!embed || !w || !bias || !idx) return REC_E_ARG;
-  switch (E) {
-    case 4: FWD_VEC(1); break;
-    case 8: FWD_VEC(2); break;
-    case 16: FWD_VEC(4); break;
-    case 32: FWD_VEC(8); break;
-    case 64: FWD_VEC(16); break;
-    default:
-      if (E <= 1) FWD_GEN(1, 1);
-      else if (E <= 2) FWD_GEN(2, 1);
-      else if (E <= 4) FWD_GEN(4, 1);
-      else if (E <= 8) FWD_GEN(8, 1);
-      else if (E <= 16) FWD_GEN(16, 1);
-      else if (E <= 32) FWD_GEN(32, 1);
-      else if (E <= 64) FWD_GEN(64, 1);
-      else if (E <= 128) FWD_GEN(64, 2);
-      else FWD_GEN(64, 4);
+  if (V >= (int64_t(1) << 31)) return REC_E_UNSUPPORTED;
+  FwdArgs a{embed, ld_e, w, ld_w, bias, V, E, idx, B, F, z, prob, emb_out, sumvec, oob_flag, as_stream(stream)};
+  bool done = false;
+  bool out_ok = (!emb_out || (reinterpret_cast<uintptr_t>(emb_out) & 15) == 0) &&
+                (!sumvec || (reinterpret_cast<uintptr_t>(sumvec) & 15) == 0);
+  if (vec4_ok(embed, E, ld_e) && out_ok) {
+    // fused layout: w is float E of the embed row and the row is a power-of-two number of float4 lanes
+    bool fused = (w == embed + E) && ld_w == ld_e && ld_e > E && (ld_e & (ld_e - 1)) == 0 && ld_e <= 64;
+    if (fused) done = dispatch_lpr<true>(a, (int)(ld_e / 4));
+    if (!done && (E & (E - 1)) == 0 && E <= 64) done = dispatch_lpr<false>(a, E / 4);
+  }
+  if (!done) {
+    if (E <= 1) FWD_GEN(1, 1);
+    else if (E <= 2) FWD_GEN(2, 1);
+    else if (E <= 4) FWD_GEN(4, 1);
+    else if (E <= 8) FWD_GEN(8, 1);
+    else if (E <= 16) FWD_GEN(16, 1);
+    else if (E <= 32) FWD_GEN(32, 1);
+    else if (E <= 64) FWD_GEN(64, 1);
+    else if (E <= 128) FWD_GEN(64, 2);
+    else FWD_GEN(64, 4);
   }
   REC_LAUNCH_CHECK();
   return REC_OK;
@@ -295,7 +334,7 @@ extern "C" int rec_emb_fm_fwd_f32(const float* embed, const float* w, const floa
 // K4 values
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void emb_fm_bwd_vals_kernel(
-    const float* __restrict__ embed, int64_t V, int E, const int64_t* __restrict__ idx, int64_t B, int F,
+    const float* __restrict__ embed, int64_t ld_e, int64_t V, int E, const int64_t* __restrict__ idx, int64_t B, int F,
     const float* __restrict__ gz, const float* __restrict__ sumvec, const float* __restrict__ emb_rows,
     const float* __restrict__ extra, float* __restrict__ dvals) {
   int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -309,7 +348,7 @@ __global__ __launch_bounds__(256) void emb_fm_bwd_vals_kernel(
     e = emb_rows[t];
   } else {
     int64_t id = idx[j];
-    e = ((uint64_t)id < (uint64_t)V) ? embed[id * E + d] : 0.f;
+    e = ((uint64_t)id < (uint64_t)V) ? embed[id * ld_e + d] : 0.f;
   }
   float v = gz[b] * (sumvec[b * E + d] - e);
   if (extra) v += extra[t];
@@ -317,8 +356,8 @@ __global__ __launch_bounds__(256) void emb_fm_bwd_vals_kernel(
 }
 
 __global__ __launch_bounds__(256) void emb_fm_bwd_vals_vec_kernel(
-    const float4* __restrict__ embed, int64_t V, int lpr, const int64_t* __restrict__ idx, int64_t B, int F,
-    const float* __restrict__ gz, const float4* __restrict__ sumvec, const float4* __restrict__ emb_rows,
+    const float* __restrict__ embed, int64_t ld_e, int64_t V, int lpr, const int64_t* __restrict__ idx, int64_t B,
+    int F, const float* __restrict__ gz, const float4* __restrict__ sumvec, const float4* __restrict__ emb_rows,
     const float4* __restrict__ extra, float4* __restrict__ dvals) {
   int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   int64_t total = B * F * lpr;
@@ -331,7 +370,8 @@ __global__ __launch_bounds__(256) void emb_fm_bwd_vals_vec_kernel(
     e = emb_rows[t];
   } else {
     int64_t id = idx[j];
-    e = ((uint64_t)id < (uint64_t)V) ? embed[id * lpr + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    e = ((uint64_t)id < (uint64_t)V) ? *reinterpret_cast<const float4*>(embed + id * ld_e + 4 * c)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   float g = gz[b];
   float4 s = sumvec[b * lpr + c];
@@ -343,20 +383,23 @@ __global__ __launch_bounds__(256) void emb_fm_bwd_vals_vec_kernel(
   dvals[t] = v;
 }
 
-extern "C" int rec_emb_fm_bwd_vals_f32(const float* embed, int64_t V, int E, const int64_t* idx, int64_t B,
-                                       int F, const float* gz, const float* sumvec, const float* emb_rows,
+extern "C" int rec_emb_fm_bwd_vals_f32(const float* embed, int64_t ld_e, int64_t V, int E, const int64_t* idx,
+                                       int64_t B, int F, const float* gz, const float* sumvec, const float* emb_rows,
                                        const float* extra, float* dvals, void* stream) {
-  if (E <= 0 || F <= 0 || B < 0) return REC_E_ARG;
+  if (E <= 0 || F <= 0 || B < 0 || (embed && ld_e < E)) return REC_E_ARG;
   if (B == 0) return REC_OK;
   if ((!embed && !emb_rows) || !idx || !gz || !sumvec || !dvals) return REC_E_ARG;
-  if (E % 4 == 0) {
+  bool al = (reinterpret_cast<uintptr_t>(sumvec) & 15) == 0 && (reinterpret_cast<uintptr_t>(dvals) & 15) == 0 &&
+            (!emb_rows || (reinterpret_cast<uintptr_t>(emb_rows) & 15) == 0) &&
+            (!extra || (reinterpret_cast<uintptr_t>(extra) & 15) == 0);
+  if (E % 4 == 0 && al && (emb_rows || vec4_ok(embed, E, ld_e))) {
     int lpr = E / 4;
     hipLaunchKernelGGL(emb_fm_bwd_vals_vec_kernel, dim3((unsigned)ceil_div64(B * F * lpr, 256)), dim3(256), 0,
-                       as_stream(stream), (const float4*)embed, V, lpr, idx, B, F, gz, (const float4*)sumvec,
+                       as_stream(stream), embed, ld_e, V, lpr, idx, B, F, gz, (const float4*)sumvec,
                        (const float4*)emb_rows, (const float4*)extra, (float4*)dvals);
   } else {
     hipLaunchKernelGGL(emb_fm_bwd_vals_kernel, dim3((unsigned)ceil_div64(B * F * E, 256)), dim3(256), 0,
-                       as_stream(stream), embed, V, E, idx, B, F, gz, sumvec, emb_rows, extra, dvals);
+                       as_stream(stream), embed, ld_e, V, E, idx, B, F, gz, sumvec, emb_rows, extra, dvals);
   }
   REC_LAUNCH_CHECK();
   return REC_OK;

@@ -99,7 +99,7 @@ class DeepFMTrainStep:
         if optimizer is not None:
             self.state = {}
             for name, p in layer.named_parameters():
-                self.state[name] = (torch.zeros_like(p), torch.zeros_like(p))
+                self.state[name] = (torch.zeros(p.shape, **f32), torch.zeros(p.shape, **f32))   # dense m, v
             self.side_e = torch.empty((n, 3, E), **f32)
             self.side_w = torch.empty((n, 3, 1), **f32)
         self.colsum_ws = torch.empty(lib.rec_colsum_workspace_bytes(B, max(u1, u2)) // 4 + 1, **f32)
@@ -119,8 +119,8 @@ class DeepFMTrainStep:
         K2, b2 = L.MLP_layer2.kernel_0, L.MLP_layer2.bias_0
         P = _Program()
         # ---- forward
-        P.add("rec_emb_fm_fwd_f32", _p(emb), _p(w), _p(bias), V, E, _p(self.X), B, F, _p(self.z_fm), None,
-              _p(self.rows), _p(self.S), _p(self.oob))
+        P.add("rec_emb_fm_fwd_f32", _p(emb), emb.stride(0), _p(w), w.stride(0), _p(bias), V, E, _p(self.X), B, F,
+              _p(self.z_fm), None, _p(self.rows), _p(self.S), _p(self.oob))
         P.add("rec_gemm_f32", 0, 0, B, u1, D, _p(self.rows), D, _p(K0), u1, _p(self.h1), u1, ops.EPI_BIAS_RELU, _p(b0),
               None, 0, None, 0, 1, None)
         P.add("rec_gemm_f32", 0, 0, B, u2, u1, _p(self.h1), u1, _p(K1), u2, _p(self.h2), u2, ops.EPI_BIAS_RELU, _p(b1),
@@ -152,8 +152,8 @@ class DeepFMTrainStep:
         P.add("rec_gemm_f32", 0, 1, B, D, u1, _p(self.dh1), u1, _p(K0), u1, _p(self.drows), D, ops.EPI_NONE, None, None,
               0, None, 0, 1, None)
         # ---- tables: IndexedSlices values, de-duplication, segment sums
-        P.add("rec_emb_fm_bwd_vals_f32", _p(emb), V, E, _p(self.X), B, F, _p(self.dz), _p(self.S), _p(self.rows),
-              _p(self.drows), _p(self.vals))
+        P.add("rec_emb_fm_bwd_vals_f32", _p(emb), emb.stride(0), V, E, _p(self.X), B, F, _p(self.dz), _p(self.S),
+              _p(self.rows), _p(self.drows), _p(self.vals))
         P.add("rec_dedup_plan_i64", _p(self.X), B * F, V, _p(self.uniq_ids), _p(self.seg_start), _p(self.perm),
               _p(self.n_uniq), _p(self.dedup_ws), self.dedup_bytes)
         P.add("rec_segment_sum_f32", _p(self.vals), E, _p(self.perm), _p(self.seg_start), B * F, 1,
@@ -175,11 +175,11 @@ class DeepFMTrainStep:
                                     ("w.embeddings", self.g_w_rows, self.side_w, 1)):
             m, v = self.state[name]
             if self.optimizer == "keras_adam":
-                P.add("rec_adam_sparse_keras_f32", _p(params[name]), _p(m), _p(v), self.V, E, _p(self.uniq_ids),
-                      _p(rows), _p(self.n_uniq), n, _p(side), t, lr, b1, b2, eps)
+                P.add("rec_adam_sparse_keras_f32", _p(params[name]), params[name].stride(0), _p(m), _p(v), self.V, E,
+                      _p(self.uniq_ids), _p(rows), _p(self.n_uniq), n, _p(side), t, lr, b1, b2, eps)
             else:
-                P.add("rec_adam_rows_f32", _p(params[name]), _p(m), _p(v), self.V, E, _p(self.uniq_ids), _p(rows),
-                      _p(self.n_uniq), n, t, lr, b1, b2, eps)
+                P.add("rec_adam_rows_f32", _p(params[name]), params[name].stride(0), _p(m), _p(v), self.V, E,
+                      _p(self.uniq_ids), _p(rows), _p(self.n_uniq), n, t, lr, b1, b2, eps)
         return P
 
     # -- execution ----------------------------------------------------------------------------------

@@ -81,6 +81,39 @@ class Layer(torch.nn.Module):
         if flag is not None and int(flag.item()) != 0:
             raise IndexError("embedding id out of range [0, feature_dims)")
 
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        post = getattr(self, "_post_apply", None)
+        if post is not None:
+            post()                  # e.g. re-establish the fused table layout after .cuda()/.to()
+        return out
+
+
+class _FMTables:
+    """Mixin of the FM-family layers: keep ``embed.embeddings`` [V,E] and ``w.embeddings`` [V,1] as two strided
+    views of ONE device array [V, ld] (row = [embed | w | pad], ld = next_pow2(E+1) >= 16) so that both values
+    of an id arrive in the same 128-byte line.  The two Parameters keep their reference names and shapes
+    (``state_dict``, ``copy_``, sparse gradients all work); only their strides change."""
+
+    def fuse_tables(self):
+        e, w = self.embed.embeddings, self.w.embeddings
+        V, E = e.shape
+        if not e.is_cuda or E % 4 != 0:
+            return False
+        ld = ops.fused_row_stride(E)
+        if e.stride(0) == ld and w.stride(0) == ld and w.data_ptr() == e.data_ptr() + 4 * E:
+            return True
+        storage = torch.zeros((V, ld), dtype=torch.float32, device=e.device)
+        storage[:, :E].copy_(e.data)
+        storage[:, E:E + 1].copy_(w.data)
+        self.embed.embeddings = torch.nn.Parameter(storage[:, :E], requires_grad=e.requires_grad)
+        self.w.embeddings = torch.nn.Parameter(storage[:, E:E + 1], requires_grad=w.requires_grad)
+        self._fused_storage = storage
+        return True
+
+    def _post_apply(self):
+        self.fuse_tables()
+
 
 def assemble_index(inputs, feature_names):
     """expand_dims(rank-1) + concat(axis=1)  (2.FM/CustomLayers.py:138-144) -> X [B,F] int64, on the GPU."""
@@ -155,7 +188,7 @@ class MLPLayer(Layer):
         return x
 
 
-class FMRankingLayer(Layer):
+class FMRankingLayer(_FMTables, Layer):
     def __init__(self, feature_names=["item_tag1", "item_tag2", "item_tag3"], feature_dims=20, embedding_dims=16,
                  **kwargs):
         super().__init__()
@@ -175,7 +208,7 @@ class FMRankingLayer(Layer):
         return {"output": output}
 
 
-class DeepFMRankingLayer(Layer):
+class DeepFMRankingLayer(_FMTables, Layer):
     def __init__(self, feature_names=["user_tag0", "user_tag1", "item_tag1", "item_tag2", "item_tag3"],
                  feature_dims=20, embedding_dims=16, mlp_dims=[32, 8], **kwargs):
         super().__init__()

@@ -43,6 +43,23 @@ def _i64(t, name):
     return _req(t, torch.int64, name)
 
 
+def _table(t, name):
+    """A table may be a strided row view (fused layout): 2-D fp32 CUDA with unit inner stride."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("%s must be a tensor on the MI355X: the HIP path has no CPU fallback" % name)
+    if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+        raise ValueError("%s must be a 2-D fp32 table with unit inner stride" % name)
+    return t
+
+
+def fused_row_stride(E):
+    """Row stride (floats) of the fused [embed(E) | w | pad] layout: next power of two >= E+1, at least 16."""
+    ld = 16
+    while ld < E + 1:
+        ld *= 2
+    return ld
+
+
 # ---------------------------------------------------------------------------------------------------
 # K1 / K2 / K3
 # ---------------------------------------------------------------------------------------------------
@@ -68,18 +85,18 @@ def new_flag(device):
 
 
 def emb_gather(table, idx, oob=None):
-    _f32(table, "table"); _i64(idx, "idx")
+    _table(table, "table"); _i64(idx, "idx")
     V, E = table.shape
     out = torch.empty(tuple(idx.shape) + (E,), dtype=torch.float32, device=table.device)
-    check(lib.rec_emb_gather_f32(_ptr(table), V, E, _ptr(idx), idx.numel(), _ptr(out), _ptr(oob), _stream()),
-          "rec_emb_gather_f32")
+    check(lib.rec_emb_gather_f32(_ptr(table), V, E, table.stride(0), _ptr(idx), idx.numel(), _ptr(out), _ptr(oob),
+                                 _stream()), "rec_emb_gather_f32")
     return out
 
 
 def emb_fm_fwd(embed, w, bias, X, want_prob=False, want_rows=False, want_sum=True, oob=None):
     """Fused w(X), embed(X) and the FM sum-square trick.  Returns z [B], prob [B]|None, rows [B,F,E]|None,
     sumvec [B,E]|None."""
-    _f32(embed, "embed"); _f32(w, "w"); _f32(bias, "bias"); _i64(X, "X")
+    _table(embed, "embed"); _table(w, "w"); _f32(bias, "bias"); _i64(X, "X")
     V, E = embed.shape
     B, F = X.shape
     dev = embed.device
@@ -87,8 +104,9 @@ def emb_fm_fwd(embed, w, bias, X, want_prob=False, want_rows=False, want_sum=Tru
     prob = torch.empty(B, dtype=torch.float32, device=dev) if want_prob else None
     rows = torch.empty((B, F, E), dtype=torch.float32, device=dev) if want_rows else None
     S = torch.empty((B, E), dtype=torch.float32, device=dev) if want_sum else None
-    check(lib.rec_emb_fm_fwd_f32(_ptr(embed), _ptr(w), _ptr(bias), V, E, _ptr(X), B, F, _ptr(z), _ptr(prob),
-                                 _ptr(rows), _ptr(S), _ptr(oob), _stream()), "rec_emb_fm_fwd_f32")
+    check(lib.rec_emb_fm_fwd_f32(_ptr(embed), embed.stride(0), _ptr(w), w.stride(0), _ptr(bias), V, E, _ptr(X), B, F,
+                                 _ptr(z), _ptr(prob), _ptr(rows), _ptr(S), _ptr(oob), _stream()),
+          "rec_emb_fm_fwd_f32")
     return z, prob, rows, S
 
 
@@ -97,8 +115,9 @@ def emb_fm_bwd_vals(embed, X, gz, sumvec, rows=None, extra=None):
     V, E = embed.shape
     B, F = X.shape
     out = torch.empty((B * F, E), dtype=torch.float32, device=embed.device)
-    check(lib.rec_emb_fm_bwd_vals_f32(_ptr(embed), V, E, _ptr(X), B, F, _ptr(_f32(gz, "gz")), _ptr(sumvec),
-                                      _ptr(rows), _ptr(extra), _ptr(out), _stream()), "rec_emb_fm_bwd_vals_f32")
+    check(lib.rec_emb_fm_bwd_vals_f32(_ptr(embed), embed.stride(0), V, E, _ptr(X), B, F, _ptr(_f32(gz, "gz")),
+                                      _ptr(sumvec), _ptr(rows), _ptr(extra), _ptr(out), _stream()),
+          "rec_emb_fm_bwd_vals_f32")
     return out
 
 
@@ -272,14 +291,16 @@ def adam_sparse_keras(var, m, v, uniq_ids, g_rows, n_uniq, t, lr, b1=0.9, b2=0.9
     V, E = var.shape
     cap = g_rows.shape[0]
     side = torch.empty((cap, 3, E), dtype=torch.float32, device=var.device)
-    check(lib.rec_adam_sparse_keras_f32(_ptr(var), _ptr(m), _ptr(v), V, E, _ptr(uniq_ids), _ptr(g_rows), _ptr(n_uniq),
-                                        cap, _ptr(side), t, lr, b1, b2, eps, _stream()), "rec_adam_sparse_keras_f32")
+    check(lib.rec_adam_sparse_keras_f32(_ptr(_table(var, "var")), var.stride(0), _ptr(m), _ptr(v), V, E, _ptr(uniq_ids),
+                                        _ptr(g_rows), _ptr(n_uniq), cap, _ptr(side), t, lr, b1, b2, eps, _stream()),
+          "rec_adam_sparse_keras_f32")
 
 
 def adam_rows(var, m, v, uniq_ids, g_rows, n_uniq, t, lr, b1=0.9, b2=0.999, eps=1e-7):
     V, E = var.shape
-    check(lib.rec_adam_rows_f32(_ptr(var), _ptr(m), _ptr(v), V, E, _ptr(uniq_ids), _ptr(g_rows), _ptr(n_uniq),
-                                g_rows.shape[0], t, lr, b1, b2, eps, _stream()), "rec_adam_rows_f32")
+    check(lib.rec_adam_rows_f32(_ptr(_table(var, "var")), var.stride(0), _ptr(m), _ptr(v), V, E, _ptr(uniq_ids),
+                                _ptr(g_rows), _ptr(n_uniq), g_rows.shape[0], t, lr, b1, b2, eps, _stream()),
+          "rec_adam_rows_f32")
 
 
 # ---------------------------------------------------------------------------------------------------

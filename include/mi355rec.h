@@ -57,25 +57,30 @@ int rec_version(void);
 int rec_index_pack_i64(const int64_t* const* cols_host, int F, int64_t rows, int64_t* X, int64_t ldx,
                        int64_t col0, void* stream);
 
-/* ---- K2  Embedding(V,E)(X) -> gather (2.FM/CustomLayers.py:129-134,146-147).  out[i,:] = table[idx[i],:]. */
-int rec_emb_gather_f32(const float* table, int64_t V, int E, const int64_t* idx, int64_t n, float* out,
-                       int* oob_flag, void* stream);
+/* Tables: row-major fp32 with a row stride `ld` >= E floats (dense table: ld = E).  The FM-family layers keep
+ * `embed` [V,E] and `w` [V,1] of one id in ONE 128-byte line -- fused layout, row = [embed(E) | w | pad] with
+ * ld = next_pow2(E+1) >= 16, passed as embed = base, w = base + E, ld_e = ld_w = ld -- because a random row
+ * read costs one 128-B line request whatever its size (measured), so the first-order weight is free.
+ *
+ * ---- K2  Embedding(V,E)(X) -> gather (2.FM/CustomLayers.py:129-134,146-147).  out[i,:] = table[idx[i],:]. */
+int rec_emb_gather_f32(const float* table, int64_t V, int E, int64_t ld, const int64_t* idx, int64_t n,
+                       float* out, int* oob_flag, void* stream);
 
 /* ---- K2+K3 fused: w(X), embed(X), reduce_sum / square / subtract / 0.5*reduce_sum
  * (2.FM/CustomLayers.py:146-153, 289-297).  z[b] = bias + sum_f w[X[b,f]] + 0.5*sum_d(S_d^2 - sum_f e_fd^2).
  * Optional outputs (NULL to skip): prob[b] = sigmoid(z[b]) (FMRankingLayer, :155); emb_out [B,F,E] (the
  * Flatten() input of DeepFM's DNN part, :300); sumvec [B,E] = S (saved for backward). */
-int rec_emb_fm_fwd_f32(const float* embed, const float* w, const float* bias, int64_t V, int E,
-                       const int64_t* idx, int64_t B, int F, float* z, float* prob, float* emb_out,
-                       float* sumvec, int* oob_flag, void* stream);
+int rec_emb_fm_fwd_f32(const float* embed, int64_t ld_e, const float* w, int64_t ld_w, const float* bias,
+                       int64_t V, int E, const int64_t* idx, int64_t B, int F, float* z, float* prob,
+                       float* emb_out, float* sumvec, int* oob_flag, void* stream);
 
 /* ---- K4 (values): GradientTape gradient of the FM part w.r.t. the gathered rows, as the IndexedSlices
  * values TF produces (2.FM/ModelManager.py:176-177): dvals[b,f,:] = gz[b]*(S[b,:] - e[b,f,:]) + extra[b,f,:].
  * emb_rows (optional): the rows saved by the forward; NULL -> re-gather from `embed`.  extra (optional):
  * gradient arriving through the DNN part. */
-int rec_emb_fm_bwd_vals_f32(const float* embed, int64_t V, int E, const int64_t* idx, int64_t B, int F,
-                            const float* gz, const float* sumvec, const float* emb_rows, const float* extra,
-                            float* dvals, void* stream);
+int rec_emb_fm_bwd_vals_f32(const float* embed, int64_t ld_e, int64_t V, int E, const int64_t* idx, int64_t B,
+                            int F, const float* gz, const float* sumvec, const float* emb_rows,
+                            const float* extra, float* dvals, void* stream);
 
 /* ---- K4 (de-duplication): what Keras' optimizer does to an IndexedSlices gradient before applying it
  * (tf.unique + unsorted_segment_sum); here ids come out ASCENDING and rows of one id are added in a fixed
@@ -152,12 +157,13 @@ int rec_adam_dense_f32(float* var, float* m, float* v, const float* g, int64_t n
                        float b1, float b2, float eps, void* stream);
 /* Keras sparse apply = DENSE SWEEP: m*=b1, v*=b2 on all V rows, m[ids]+=(1-b1)g, v[ids]+=(1-b2)g^2, then
  * var -= lr_t*m/(sqrt(v)+eps) on all V rows.  (uniq_ids, g_rows, n_uniq) as produced by the dedup above
- * (cap = allocated rows of uniq_ids/g_rows).  side: workspace of cap*3*E floats. */
-int rec_adam_sparse_keras_f32(float* var, float* m, float* v, int64_t V, int E, const int64_t* uniq_ids,
-                              const float* g_rows, const int64_t* n_uniq, int64_t cap, float* side,
-                              int64_t t, float lr, float b1, float b2, float eps, void* stream);
+ * (cap = allocated rows of uniq_ids/g_rows).  var has row stride ld; m, v are dense [V,E].
+ * side: workspace of cap*3*E floats. */
+int rec_adam_sparse_keras_f32(float* var, int64_t ld, float* m, float* v, int64_t V, int E,
+                              const int64_t* uniq_ids, const float* g_rows, const int64_t* n_uniq, int64_t cap,
+                              float* side, int64_t t, float lr, float b1, float b2, float eps, void* stream);
 /* 'lazy' variant (NOT reference semantics): only the touched rows decay and move. */
-int rec_adam_rows_f32(float* var, float* m, float* v, int64_t V, int E, const int64_t* uniq_ids,
+int rec_adam_rows_f32(float* var, int64_t ld, float* m, float* v, int64_t V, int E, const int64_t* uniq_ids,
                       const float* g_rows, const int64_t* n_uniq, int64_t cap, int64_t t, float lr,
                       float b1, float b2, float eps, void* stream);
 

@@ -260,3 +260,19 @@ def test_mlp_layer_errors_and_lazy_build(R):
     bs = [mlp.bias_0.detach().cpu().numpy(), mlp.bias_1.detach().cpu().numpy()]
     ref = L.mlp_forward(x, ks, bs, "tanh", np.float64)
     assert np.abs(y.detach().cpu().numpy() - ref).max() <= 1e-5
+
+
+def test_fm_tables_are_fused_on_device(R):
+    """embed [V,E] and w [V,1] become two views of one [V, ld] array on the GPU (one 128-B line per id)."""
+    layer = R.layers.DeepFMRankingLayer(feature_names=["a", "b", "c"], feature_dims=1000, embedding_dims=16)
+    e0 = layer.embed.embeddings.detach().clone()
+    w0 = layer.w.embeddings.detach().clone()
+    layer = layer.cuda()
+    e, w = layer.embed.embeddings, layer.w.embeddings
+    assert tuple(e.shape) == (1000, 16) and tuple(w.shape) == (1000, 1)
+    assert e.stride() == (32, 1) and w.stride() == (32, 1) and w.data_ptr() == e.data_ptr() + 64
+    assert torch.equal(e.detach().cpu(), e0) and torch.equal(w.detach().cpu(), w0)
+    sd = layer.state_dict()
+    assert set(sd) >= {"embed.embeddings", "w.embeddings", "bias"}
+    layer.load_state_dict(sd)                                       # round trip by reference names
+    assert layer.embed.embeddings.stride() == (32, 1)

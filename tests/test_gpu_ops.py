@@ -361,3 +361,34 @@ def test_shard_bucketize_bit_exact(ops, P, zipf):
         start += c
     back = ops.permute_rows(torch.cat(got), perm, scatter=True).cpu().numpy()
     assert np.array_equal(back, tab[ids])
+
+
+# ---------------------------------------------------------------------------------------------
+# strided tables / fused [embed | w | pad] rows
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("E", [4, 8, 16, 32])
+@pytest.mark.parametrize("B,F", [(300, 26), (8192, 26), (33, 1), (100, 40)])
+def test_fused_table_layout_matches_separate_tables(ops, E, B, F):
+    V = 5000
+    pr = H.deepfm_params(E + F, V, F, E, scale=0.4)
+    X = field_ids(B + E, B, F, V, 1.1)
+    ld = ops.fused_row_stride(E)
+    assert ld >= E + 1 and ld & (ld - 1) == 0
+    storage = torch.zeros((V, ld), device="cuda")
+    storage[:, :E] = dev(pr["embed"])
+    storage[:, E:E + 1] = dev(pr["w"])
+    emb_v, w_v = storage[:, :E], storage[:, E:E + 1]
+    z1, p1, r1, s1 = ops.emb_fm_fwd(emb_v, w_v, dev(pr["bias"]), dev(X), want_prob=True, want_rows=True)
+    z2, p2, r2, s2 = ops.emb_fm_fwd(dev(pr["embed"]), dev(pr["w"]), dev(pr["bias"]), dev(X), want_prob=True,
+                                    want_rows=True)
+    p64, z64 = L.fm_forward(pr["embed"], pr["w"], pr["bias"], X, np.float64)
+    for z in (z1, z2):
+        assert np.abs(z.cpu().numpy() - z64[:, 0]).max() <= 1e-5 * max(1.0, np.abs(z64).max())
+    assert torch.equal(r1, r2) and np.array_equal(r1.cpu().numpy(), pr["embed"][X])
+    assert np.abs(s1.cpu().numpy() - s2.cpu().numpy()).max() <= 1e-6
+    # strided gather and strided re-gather in the backward values
+    assert np.array_equal(ops.emb_gather(emb_v, dev(X)).cpu().numpy(), pr["embed"][X])
+    gz = dev(H.rng(1).normal(size=(B,)).astype(np.float32))
+    v1 = ops.emb_fm_bwd_vals(emb_v, dev(X), gz, s1, None, None)
+    v2 = ops.emb_fm_bwd_vals(dev(pr["embed"]), dev(X), gz, s1, r1, None)
+    assert torch.equal(v1, v2)
