@@ -21,7 +21,8 @@ SIGNATURES = {
     "rec_emb_fm_bwd_vals_f32": (i32, [p, i64, i64, i32, p, i64, i32, p, p, p, p, p, p]),
     "rec_dedup_workspace_bytes": (sz, [i64]),
     "rec_dedup_plan_i64": (i32, [p, i64, i64, p, p, p, p, p, sz, p]),
-    "rec_segment_sum_f32": (i32, [p, i32, p, p, i64, i32, p, p]),
+    "rec_segment_sum_workspace_bytes": (sz, [i64, i32]),
+    "rec_segment_sum_f32": (i32, [p, i32, p, p, i64, i32, p, p, p]),
     "rec_gemm_f32": (i32, [i32, i32, i64, i64, i64, p, i64, p, i64, p, i64, i32, p, p, i64, p, i64, i32, p, p]),
     "rec_act_fwd_f32": (i32, [i32, p, p, p, i64, p]),
     "rec_crossnet_mat_bwd_elem_f32": (i32, [p, p, p, p, p, i32, i64, p]),
@@ -42,6 +43,18 @@ SIGNATURES = {
     "rec_shard_bucketize_workspace_bytes": (sz, [i64, i32]),
     "rec_shard_bucketize_i64": (i32, [p, i64, i64, i32, p, p, p, p, p, sz, p]),
     "rec_permute_rows_f32": (i32, [p, p, i64, i32, i32, p, p]),
+    "rec_din_prepare_f32": (i32, [p, p, i32, i32, p, p, p, p]),
+    "rec_din_prepare_bwd_f32": (i32, [p, p, i32, i32, p, p]),
+    "rec_din_attn_fwd_f32": (i32, [p, i64, i64, i32, i32, p, i64, i32, p, p, i32, i32, p, p, p, p, p, i64, i32, p, p, p,
+                                   p]),
+    "rec_din_attn_bwd_f32": (i32, [p, i64, i64, i32, i32, p, i64, i32, p, p, i32, i32, p, p, p, p, p, i64, i32, p, p, p,
+                                   p, p, p, p, p]),
+    "rec_feat_act_fwd_f32": (i32, [i32, p, p, p, p, p, i64, i32, p]),
+    "rec_feat_act_bwd_f32": (i32, [i32, p, p, p, p, p, p, p, i64, i32, p]),
+    "rec_layernorm_fwd_f32": (i32, [p, p, p, i64, i32, p, p, p, p]),
+    "rec_layernorm_bwd_f32": (i32, [p, p, p, p, i64, i32, p, p, p]),
+    "rec_softmax_fwd_f32": (i32, [p, i64, i32, p, p]),
+    "rec_softmax_bwd_f32": (i32, [p, p, i64, i32, p, p]),
 }
 
 

@@ -5,6 +5,10 @@
 //
 // The key/position radix sort is rocPRIM's device primitive (header-only, compiled here for gfx950); the
 // run detection, compaction and the segment sums are hand-written.
+//
+// Hot ids (a Zipf head, or DIN's padding id that fills half of every behaviour series) give runs of 10^5 rows;
+// a run longer than LONG rows is therefore cut into chunks of CH sorted positions that separate workgroups sum
+// (fixed slot order + fixed LDS tree), and the owner of the run adds the chunk partials in chunk order.
 #include "common.h"
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -12,6 +16,8 @@
 namespace {
 
 constexpr int TILE = 1024;  // sorted keys per workgroup in the run-detection kernels (256 threads x 4)
+constexpr int CH = 256;     // chunk of sorted positions in the long-run path
+constexpr int LONG = 256;   // runs longer than this take the chunked path (LONG >= CH: <= 2 long runs per chunk)
 
 struct Layout {
   size_t keys_in, keys_out, pos_in, tile_heads, sort_tmp, sort_tmp_bytes, total;
@@ -136,21 +142,70 @@ __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t* __restric
   }
 }
 
-// One lane group (LPR lanes x float4) per unique id; rows of the run are added in sorted (= position) order.
+// ---- long runs: chunk partials.  One workgroup per chunk of CH sorted positions; threads = (slot, dim) with
+// GE = power of two >= E dims per slot.  part[(chunk*2 + which)*E + d]; which = 0: the run that covers the chunk's
+// first position, 1: a long run that starts inside the chunk.
+template <int GE>
+__global__ __launch_bounds__(256) void segsum_chunk_kernel(const float* __restrict__ vals, int E,
+                                                           const int32_t* __restrict__ perm,
+                                                           const int32_t* __restrict__ seg_start, int64_t n,
+                                                           int32_t row_div, float* __restrict__ part) {
+  constexpr int NS = 256 / GE;   // row slots
+  __shared__ float red[256];
+  const int tid = threadIdx.x, slot = tid / GE, d = tid % GE;
+  const int c0 = blockIdx.x * CH;
+  const int c1 = (c0 + CH < n) ? c0 + CH : (int)n;
+  // largest u with seg_start[u] <= c0 (the padded tail holds n > c0, so it is never chosen)
+  int lo = 0, hi = (int)n;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (seg_start[mid] <= c0) lo = mid; else hi = mid - 1;
+  }
+  for (int u = lo; u < (int)n && seg_start[u] < c1; ++u) {
+    int s0 = seg_start[u], s1 = seg_start[u + 1];
+    if (s1 - s0 <= LONG) continue;
+    int a = s0 > c0 ? s0 : c0, b = s1 < c1 ? s1 : c1;
+    float acc = 0.f;
+    if (d < E)
+      for (int s = a + slot; s < b; s += NS) acc += vals[(int64_t)(perm[s] / row_div) * E + d];
+    red[tid] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int k = NS / 2; k > 0; k >>= 1) {   // fixed tree over the slots
+      if (slot < k) red[tid] += red[tid + k * GE];
+      __syncthreads();
+    }
+    int which = s0 <= c0 ? 0 : 1;
+    if (slot == 0 && d < E) part[((int64_t)blockIdx.x * 2 + which) * E + d] = red[d];
+    __syncthreads();
+  }
+}
+
+// One lane group (LPR lanes x float4) per unique id; rows of the run are added in sorted (= position) order;
+// long runs add their chunk partials in chunk order.
 __global__ __launch_bounds__(256) void segsum_vec_kernel(const float4* __restrict__ vals, int lpr,
                                                          const int32_t* __restrict__ perm,
                                                          const int32_t* __restrict__ seg_start, int64_t n,
-                                                         int32_t row_div, float4* __restrict__ out) {
+                                                         int32_t row_div, const float4* __restrict__ part,
+                                                         float4* __restrict__ out) {
   int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n * lpr) return;
   int64_t u = t / lpr;
   int c = (int)(t - u * lpr);
   int s0 = seg_start[u], s1 = seg_start[u + 1];
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s = s0; s < s1; ++s) {
-    int64_t src = perm[s] / row_div;
-    float4 v = vals[src * lpr + c];
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  if (s1 - s0 <= LONG) {
+    for (int s = s0; s < s1; ++s) {
+      int64_t src = perm[s] / row_div;
+      float4 v = vals[src * lpr + c];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  } else {
+    for (int ch = s0 / CH; ch <= (s1 - 1) / CH; ++ch) {
+      int which = s0 <= ch * CH ? 0 : 1;
+      float4 v = part[((int64_t)ch * 2 + which) * lpr + c];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
   }
   out[t] = acc;
 }
@@ -158,16 +213,24 @@ __global__ __launch_bounds__(256) void segsum_vec_kernel(const float4* __restric
 __global__ __launch_bounds__(256) void segsum_scalar_kernel(const float* __restrict__ vals, int E,
                                                             const int32_t* __restrict__ perm,
                                                             const int32_t* __restrict__ seg_start, int64_t n,
-                                                            int32_t row_div, float* __restrict__ out) {
+                                                            int32_t row_div, const float* __restrict__ part,
+                                                            float* __restrict__ out) {
   int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n * E) return;
   int64_t u = t / E;
   int d = (int)(t - u * E);
   int s0 = seg_start[u], s1 = seg_start[u + 1];
   float acc = 0.f;
-  for (int s = s0; s < s1; ++s) {
-    int64_t src = perm[s] / row_div;
-    acc += vals[src * E + d];
+  if (s1 - s0 <= LONG) {
+    for (int s = s0; s < s1; ++s) {
+      int64_t src = perm[s] / row_div;
+      acc += vals[src * E + d];
+    }
+  } else {
+    for (int ch = s0 / CH; ch <= (s1 - 1) / CH; ++ch) {
+      int which = s0 <= ch * CH ? 0 : 1;
+      acc += part[((int64_t)ch * 2 + which) * E + d];
+    }
   }
   out[t] = acc;
 }
@@ -216,17 +279,41 @@ extern "C" int rec_dedup_plan_i64(const int64_t* ids, int64_t n, int64_t V, int6
   return REC_OK;
 }
 
-extern "C" int rec_segment_sum_f32(const float* vals, int E, const int32_t* perm, const int32_t* seg_start,
-                                   int64_t n, int32_t row_div, float* out, void* stream) {
-  if (!vals || !perm || !seg_start || !out || E <= 0 || n < 0 || row_div <= 0) return REC_E_ARG;
+extern "C" size_t rec_segment_sum_workspace_bytes(int64_t n, int E) {
+  if (n <= 0 || E <= 0) return 256;
+  return sizeof(float) * (size_t)ceil_div64(n, CH) * 2 * (size_t)E + 256;
+}
+
+extern "C" int rec_segment_sum_f32(const float* vals, int E, const int32_t* perm, const int32_t* seg_start, int64_t n,
+                                   int32_t row_div, float* out, float* workspace, void* stream) {
+  if (E <= 0 || n < 0 || row_div <= 0) return REC_E_ARG;
   if (n == 0) return REC_OK;
-  if (E % 4 == 0) {
+  if (!vals || !perm || !seg_start || !out || !workspace) return REC_E_ARG;
+  if (E > 256) return REC_E_UNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  unsigned n_chunks = (unsigned)ceil_div64(n, CH);
+#define CHUNK(GE) hipLaunchKernelGGL(segsum_chunk_kernel<GE>, dim3(n_chunks), dim3(256), 0, st, vals, E, perm, \
+                                     seg_start, n, row_div, workspace)
+  if (E <= 1) CHUNK(1);
+  else if (E <= 2) CHUNK(2);
+  else if (E <= 4) CHUNK(4);
+  else if (E <= 8) CHUNK(8);
+  else if (E <= 16) CHUNK(16);
+  else if (E <= 32) CHUNK(32);
+  else if (E <= 64) CHUNK(64);
+  else if (E <= 128) CHUNK(128);
+  else CHUNK(256);
+#undef CHUNK
+  REC_LAUNCH_CHECK();
+  bool vec = E % 4 == 0 && (reinterpret_cast<uintptr_t>(vals) & 15) == 0 &&
+             (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
+  if (vec) {
     int lpr = E / 4;
-    hipLaunchKernelGGL(segsum_vec_kernel, dim3((unsigned)ceil_div64(n * lpr, 256)), dim3(256), 0,
-                       as_stream(stream), (const float4*)vals, lpr, perm, seg_start, n, row_div, (float4*)out);
+    hipLaunchKernelGGL(segsum_vec_kernel, dim3((unsigned)ceil_div64(n * lpr, 256)), dim3(256), 0, st,
+                       (const float4*)vals, lpr, perm, seg_start, n, row_div, (const float4*)workspace, (float4*)out);
   } else {
-    hipLaunchKernelGGL(segsum_scalar_kernel, dim3((unsigned)ceil_div64(n * E, 256)), dim3(256), 0,
-                       as_stream(stream), vals, E, perm, seg_start, n, row_div, out);
+    hipLaunchKernelGGL(segsum_scalar_kernel, dim3((unsigned)ceil_div64(n * E, 256)), dim3(256), 0, st, vals, E, perm,
+                       seg_start, n, row_div, workspace, out);
   }
   REC_LAUNCH_CHECK();
   return REC_OK;

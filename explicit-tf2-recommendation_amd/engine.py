@@ -103,6 +103,7 @@ class DeepFMTrainStep:
             self.side_e = torch.empty((n, 3, E), **f32)
             self.side_w = torch.empty((n, 3, 1), **f32)
         self.colsum_ws = torch.empty(lib.rec_colsum_workspace_bytes(B, max(u1, u2)) // 4 + 1, **f32)
+        self.segsum_ws = torch.empty(lib.rec_segment_sum_workspace_bytes(n, E) // 4, **f32)
         self._graphs = {}
         self._static_prog = self._build_static()
 
@@ -157,8 +158,9 @@ class DeepFMTrainStep:
         P.add("rec_dedup_plan_i64", _p(self.X), B * F, V, _p(self.uniq_ids), _p(self.seg_start), _p(self.perm),
               _p(self.n_uniq), _p(self.dedup_ws), self.dedup_bytes)
         P.add("rec_segment_sum_f32", _p(self.vals), E, _p(self.perm), _p(self.seg_start), B * F, 1,
-              _p(self.g_embed_rows))
-        P.add("rec_segment_sum_f32", _p(self.dz), 1, _p(self.perm), _p(self.seg_start), B * F, F, _p(self.g_w_rows))
+              _p(self.g_embed_rows), _p(self.segsum_ws))
+        P.add("rec_segment_sum_f32", _p(self.dz), 1, _p(self.perm), _p(self.seg_start), B * F, F, _p(self.g_w_rows),
+              _p(self.segsum_ws))
         P.add("rec_colsum_f32", _p(self.dz), B, 1, 1, _p(g["bias"]), _p(self.colsum_ws))
         return P
 

@@ -205,3 +205,98 @@ class Sigmoid(torch.autograd.Function):
         (y,) = ctx.saved_tensors
         gz = ops.act_bwd(ops.ACT_SIGMOID, y, g.contiguous())
         return gz, (gz.reshape(ctx.shape2) if ctx.shape2 is not None else None)
+
+
+# ---------------------------------------------------------------------------------------------------
+# DIN (5.DIN/CustomLayers.py:142-289)
+# ---------------------------------------------------------------------------------------------------
+
+class FeatAct(torch.autograd.Function):
+    """Per-feature activation on [M,N]: Dice (inference-mode BN statistics), PReLU or a named activation."""
+
+    @staticmethod
+    def forward(ctx, x, kind, alpha, mean, var):
+        x = x.contiguous()
+        ctx.kind = kind
+        ctx.save_for_backward(x, alpha, mean, var)
+        return ops.feat_act_fwd(kind, x, alpha, mean, var)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, alpha, mean, var = ctx.saved_tensors
+        want_a = alpha is not None and ctx.needs_input_grad[2]
+        gx, ga = ops.feat_act_bwd(ctx.kind, x, gy.contiguous(), alpha, mean, var, want_alpha=want_a)
+        return gx, None, (ops.colsum(ga) if want_a else None), None, None
+
+
+class LayerNorm(torch.autograd.Function):
+    """tf.keras.layers.LayerNormalization() over the last axis, epsilon 1e-3."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        y, xhat, rstd = ops.layernorm_fwd(x.contiguous(), gamma, beta)
+        ctx.save_for_backward(xhat, rstd, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xhat, rstd, gamma = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx, gg = ops.layernorm_bwd(gy, xhat, rstd, gamma)
+        return gx, ops.colsum(gg), ops.colsum(gy)
+
+
+class Softmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = ops.softmax_fwd(x.contiguous())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return ops.softmax_bwd(y, gy.contiguous())
+
+
+class DinAttention(torch.autograd.Function):
+    """DinActivationLayer over every time step + mask + weighted sum pooling (5.DIN/CustomLayers.py:173-180,
+    256-282), bilinear-factorised.  Inputs: table, q = flattened candidate-item embedding [B,D], series ids
+    [B,T,C], the Dense(H) kernel W1 [3D+D*D,H] / bias b1, the activation's parameters, the Dense(1) kernel W2 [H,1]
+    / bias b2.  Returns pooled [B,D] and the raw scores [B,T] (not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, embed, q, series, W1, b1, kind, alpha, mean, var, W2, b2, padding_index, mask_valid, oob):
+        q = q.contiguous()
+        B, D = q.shape
+        H = W1.shape[1]
+        Wcat, Wkd, bext = ops.din_prepare(W1.contiguous(), b1.contiguous(), D, H)
+        Mext = ops.gemm(q, Wcat, epi=ops.EPI_BIAS, bias=bext)                 # [B, D*H + H] on the matrix cores
+        w2 = W2.contiguous().reshape(-1)
+        scores, pooled = ops.din_attn_fwd(embed, series, Mext, Wkd, kind, alpha, mean, var, w2, b2.contiguous(),
+                                          padding_index, mask_valid, oob)
+        ctx.save_for_backward(embed, q, series, Wcat, Wkd, Mext, alpha, mean, var, w2, b2, scores)
+        ctx.cfg = (kind, padding_index, mask_valid, D, H)
+        ctx.mark_non_differentiable(scores)
+        return pooled, scores
+
+    @staticmethod
+    def backward(ctx, gpooled, _gscores):
+        embed, q, series, Wcat, Wkd, Mext, alpha, mean, var, w2, b2, scores = ctx.saved_tensors
+        kind, padding_index, mask_valid, D, H = ctx.cfg
+        V, E = embed.shape
+        B = q.shape[0]
+        gkeys, gMext, gw2p, galphap, gb2p = ops.din_attn_bwd(embed, series, Mext, Wkd, kind, alpha, mean, var, w2, b2,
+                                                             padding_index, mask_valid, scores, gpooled.contiguous())
+        gq = ops.gemm(gMext, Wcat, transB=True)                                          # [B,D]
+        gWcat = ops.gemm(q, gMext, transA=True, split_k=ops.split_k_for(B, D, D * H + H))  # [D, D*H+H]
+        gbext = ops.colsum(gMext)
+        gWkd = ops.colsum(gMext[:, :D * H]).reshape(D, H)     # Eff_b = Wkd + M_b  =>  dWkd = sum_b dEff_b
+        gW1 = ops.din_prepare_bwd(gWcat, gWkd, D, H)
+        gb1 = gbext[D * H:].clone()
+        gW2 = ops.colsum(gw2p).reshape(H, 1)
+        galpha = ops.colsum(galphap) if alpha is not None else None
+        gb2 = ops.colsum(gb2p)
+        plan = ops.DedupPlan(series, V)
+        gembed = _sparse_grad(plan, gkeys.reshape(-1, E), E, (V, E))
+        return gembed, gq, None, gW1, gb1, None, galpha, None, None, gW2, gb2, None, None, None

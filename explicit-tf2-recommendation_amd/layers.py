@@ -435,3 +435,250 @@ class DeepCrossNetworkLayer(Layer):
         dnn_output = self.dense_layer(_input)
         combine_output = ConcatCols.apply(cross_output, dnn_output)
         return {"output": self.output_layer(combine_output)}
+
+
+# ---------------------------------------------------------------------------------------------------
+# 5.DIN
+# ---------------------------------------------------------------------------------------------------
+
+class Dice(Layer):
+    """Dice (5.DIN/CustomLayers.py:183-196): p = sigmoid(BN(x)) with BatchNormalization(center=False, scale=False),
+    out = alpha*(1-p)*x + p*x, alpha init 0.  The BN runs on its moving statistics (inference mode: mean 0,
+    variance 1 at init) -- the oracle is pinned to that mode; batch statistics inside
+    tf.vectorized_map are not reproduced."""
+
+    def __init__(self, axis=-1, epsilon=1e-9, input_dim=None):
+        super().__init__()
+        self.axis, self.epsilon = axis, epsilon
+        self.built = False
+        if input_dim is not None:
+            self.build(input_dim)
+
+    def build(self, n):
+        self.alpha = torch.nn.Parameter(torch.zeros(int(n)))
+        self.register_buffer("moving_mean", torch.zeros(int(n)))
+        self.register_buffer("moving_variance", torch.ones(int(n)))
+        self.built = True
+
+    def forward(self, x):
+        if not self.built:
+            self.build(x.shape[-1])
+            self.to(x.device)
+        return Fn.FeatAct.apply(x, ops.DACT_DICE, self.alpha, self.moving_mean, self.moving_variance)
+
+
+class PReLU(Layer):
+    """tf.keras.layers.PReLU(): max(0,x) + alpha*min(0,x), alpha per feature, init 0."""
+
+    def __init__(self, input_dim=None):
+        super().__init__()
+        self.built = False
+        if input_dim is not None:
+            self.build(input_dim)
+
+    def build(self, n):
+        self.alpha = torch.nn.Parameter(torch.zeros(int(n)))
+        self.built = True
+
+    def forward(self, x):
+        if not self.built:
+            self.build(x.shape[-1])
+            self.to(x.device)
+        return Fn.FeatAct.apply(x, ops.DACT_PRELU, self.alpha, None, None)
+
+
+class Activation(Layer):
+    """tf.keras.layers.Activation(name or callable layer)."""
+
+    def __init__(self, activation):
+        super().__init__()
+        if isinstance(activation, torch.nn.Module):
+            self.inner, self.kind = activation, None
+        else:
+            if activation not in ops.DACT_CODE:
+                raise ValueError("Unknown activation function: %r" % (activation,))
+            self.inner, self.kind = None, ops.DACT_CODE[activation]
+
+    def forward(self, x):
+        if self.inner is not None:
+            return self.inner(x)
+        return Fn.FeatAct.apply(x, self.kind, None, None, None)
+
+
+class LayerNormalization(Layer):
+    """tf.keras.layers.LayerNormalization(): last axis, epsilon 1e-3, gamma 1, beta 0."""
+
+    def __init__(self, input_dim):
+        super().__init__()
+        self.gamma = torch.nn.Parameter(torch.ones(int(input_dim)))
+        self.beta = torch.nn.Parameter(torch.zeros(int(input_dim)))
+
+    def forward(self, x):
+        return Fn.LayerNorm.apply(x, self.gamma, self.beta)
+
+
+class SoftmaxDense(Layer):
+    """Dense(units, activation='softmax')."""
+
+    def __init__(self, units, input_dim):
+        super().__init__()
+        self.dense = Dense(units, activation=None, input_dim=input_dim)
+
+    def forward(self, x):
+        return Fn.Softmax.apply(self.dense(x))
+
+
+class Sequential(Layer):
+    def __init__(self, layers_):
+        super().__init__()
+        self.layers = torch.nn.ModuleList(layers_)
+
+    def forward(self, x):
+        for l in self.layers:
+            x = l(x)
+        return x
+
+
+def make_mlp_layer(units, activation="PReLU", normalization="layernorm", softmax_units=-1, sigmoid_units=False,
+                   input_dim=None):
+    """5.DIN/CustomLayers.py:142-160.  ``input_dim`` (extension) is needed because layers are built eagerly."""
+    if input_dim is None:
+        raise ValueError("make_mlp_layer needs input_dim")
+    seq = []
+    d = input_dim
+    for unit in units:
+        seq.append(Dense(unit, input_dim=d))
+        d = unit
+        if normalization == "batchnorm":
+            raise NotImplementedError("normalization='batchnorm' is not on the hot path")
+        elif normalization == "layernorm":
+            seq.append(LayerNormalization(d))
+        if activation == "PReLU":
+            seq.append(PReLU(d))
+        elif activation == "Dice":
+            seq.append(Dice(input_dim=d))
+        elif isinstance(activation, torch.nn.Module):
+            # the reference wraps a Dice() *instance* in Activation(...) (5.DIN/CustomLayers.py:154-155,219)
+            if isinstance(activation, (Dice, PReLU)) and not activation.built:
+                activation.build(d)
+            seq.append(Activation(activation))
+        else:
+            seq.append(Activation(activation))
+    if softmax_units > 0:
+        seq.append(SoftmaxDense(softmax_units, d))
+    elif sigmoid_units:
+        seq.append(Dense(1, activation="sigmoid", input_dim=d))
+    return Sequential(seq)
+
+
+class DinActivationLayer(Layer):
+    """5.DIN/CustomLayers.py:163-180: Dense(36) -> activation -> Dense(1) over [q, q-k, k, vec(k q^T)].
+    ``call((vec1, vec2))`` scores ONE key per example like the reference; DINLayer uses the batched, fused
+    attention kernel with the same parameters."""
+
+    def __init__(self, activation="PReLU", input_dim=None, **kwargs):
+        super().__init__()
+        self._activation_spec = (activation,)     # in a tuple: a Dice() instance must register under mlp_layer only
+        self.hidden = 36
+        self.built = False
+        if input_dim is not None:
+            self.build(input_dim)
+
+    def build(self, D):
+        D = int(D)
+        self.D = D
+        self.mlp_layer = make_mlp_layer([self.hidden], activation=self._activation_spec[0], normalization="none",
+                                        input_dim=3 * D + D * D)
+        self.output_layer = Dense(1, input_dim=self.hidden)
+        self.built = True
+
+    def act_params(self):
+        act = self.mlp_layer.layers[1]
+        inner = act.inner if isinstance(act, Activation) and act.inner is not None else act
+        if isinstance(inner, Dice):
+            return ops.DACT_DICE, inner.alpha, inner.moving_mean, inner.moving_variance
+        if isinstance(inner, PReLU):
+            return ops.DACT_PRELU, inner.alpha, None, None
+        return inner.kind, None, None, None
+
+    def attend(self, embed, q, series, padding_index, mask_valid, oob=None):
+        """All T keys of every example at once: pooled [B,D], raw scores [B,T]."""
+        dense = self.mlp_layer.layers[0]
+        kind, alpha, mean, var = self.act_params()
+        return Fn.DinAttention.apply(embed, q, series, dense.kernel, dense.bias, kind, alpha, mean, var,
+                                     self.output_layer.kernel, self.output_layer.bias, padding_index, mask_valid, oob)
+
+    def forward(self, inputs):
+        vec1, vec2 = inputs                       # q [B,D], k [B,D]
+        if not self.built:
+            self.build(vec1.shape[1])
+            self.to(vec1.device)
+        # a single key per example = a length-1 "series" of already-gathered rows: gather from an identity table
+        B, D = vec2.shape
+        ids = torch.arange(B, device=vec2.device, dtype=torch.int64).reshape(B, 1, 1)
+        pooled, scores = self.attend_rows(vec1, vec2, ids)
+        return scores.reshape(B, 1)
+
+    def attend_rows(self, q, keys2d, ids):
+        dense = self.mlp_layer.layers[0]
+        kind, alpha, mean, var = self.act_params()
+        # mask_valid=1 with padding_index=-1: no position is masked
+        return Fn.DinAttention.apply(keys2d.contiguous(), q, ids, dense.kernel, dense.bias, kind, alpha, mean, var,
+                                     self.output_layer.kernel, self.output_layer.bias, -1, 1, None)
+
+
+class DINLayer(Layer):
+    """5.DIN/CustomLayers.py:199-289.  ``mask_mode='reference'`` reproduces the reference's mask (only PADDED
+    positions contribute, :256,277-278); ``'valid'`` is the intended convention."""
+
+    def __init__(self, user_and_context_categorical_features=["uid", "utag1", "utag2", "utag3", "utag4"],
+                 item_categorical_features=["i_goods_id", "i_shop_id", "i_cate_id"],
+                 behavior_series_features=["visited_goods_ids", "visited_shop_ids", "visited_cate_ids"],
+                 continuous_features=["itag4_origin", "itag4_square", "itag4_cube"], feature_dims=160000,
+                 embedding_dims=16, activation="Dice", padding_index=0, mask_mode="reference"):
+        super().__init__()
+        self.user_and_context_categorical_features = user_and_context_categorical_features
+        self.item_categorical_features = item_categorical_features
+        assert len(item_categorical_features) == len(behavior_series_features), \
+            "Features to be interacted should match in item and behavior series"
+        self.behavior_series_features = behavior_series_features
+        self.continuous_features = continuous_features
+        self.feature_dims = feature_dims
+        self.embedding_dims = embedding_dims
+        if mask_mode not in ("reference", "valid"):
+            raise ValueError("mask_mode must be 'reference' or 'valid'")
+        self.mask_mode = mask_mode
+        self.embed = Embedding(feature_dims, embedding_dims)
+        D = len(item_categorical_features) * embedding_dims
+        self.din_activation_layer = DinActivationLayer(
+            activation=Dice() if activation == "Dice" else activation, input_dim=D)
+        n_profile = len(user_and_context_categorical_features) + len(item_categorical_features)
+        self.mlp = make_mlp_layer([200, 80], activation=activation, softmax_units=2,
+                                  input_dim=n_profile * embedding_dims + D)
+        self.padding_index = padding_index
+
+    def forward(self, inputs):
+        prof_names = self.user_and_context_categorical_features + self.item_categorical_features
+        X_cate = assemble_index(inputs, prof_names)
+        flag = ops.new_flag(X_cate.device) if self.check_ids else None
+        profile = self.embed(X_cate, flag)
+        profile_output = profile.reshape(profile.shape[0], -1)
+        X_item = assemble_index(inputs, self.item_categorical_features)
+        q = self.embed(X_item, flag)
+        q = q.reshape(q.shape[0], -1)
+        series_cols = []
+        for name in self.behavior_series_features:
+            t = inputs[name]
+            if not isinstance(t, torch.Tensor):
+                t = torch.as_tensor(t)
+            t = t.to(device=X_cate.device, dtype=torch.int64).contiguous()
+            if t.dim() != 2:
+                raise ValueError("behaviour series %r must have shape [B,T]" % name)
+            series_cols.append(t)
+        B, T = series_cols[0].shape
+        series = ops.index_pack(series_cols).reshape(B, T, len(series_cols))      # tf.stack(axis=2)
+        pooled, _ = self.din_activation_layer.attend(self.embed.embeddings, q, series, self.padding_index,
+                                                     1 if self.mask_mode == "valid" else 0, flag)
+        self._raise_if_oob(flag)
+        X_combined = ConcatCols.apply(profile_output, pooled)
+        return {"output": self.mlp(X_combined)}

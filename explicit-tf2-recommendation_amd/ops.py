@@ -145,8 +145,9 @@ class DedupPlan:
     def segment_sum(self, vals, E, row_div=1):
         """vals [n/row_div, E] -> [n, E]; rows >= n_uniq are zero."""
         out = torch.empty((max(self.n, 1), E), dtype=torch.float32, device=vals.device)
+        ws = torch.empty(lib.rec_segment_sum_workspace_bytes(self.n, E) // 4, dtype=torch.float32, device=vals.device)
         check(lib.rec_segment_sum_f32(_ptr(_f32(vals, "vals")), E, _ptr(self.perm), _ptr(self.seg_start), self.n,
-                                      row_div, _ptr(out), _stream()), "rec_segment_sum_f32")
+                                      row_div, _ptr(out), _ptr(ws), _stream()), "rec_segment_sum_f32")
         return out
 
 
@@ -328,3 +329,113 @@ def permute_rows(x, perm, scatter):
     check(lib.rec_permute_rows_f32(_ptr(_f32(x, "x")), _ptr(_i64(perm, "perm")), n, E, int(scatter), _ptr(out),
                                    _stream()), "rec_permute_rows_f32")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# DIN
+# ---------------------------------------------------------------------------------------------------
+DACT_NONE, DACT_RELU, DACT_SIGMOID, DACT_TANH, DACT_DICE, DACT_PRELU = range(6)
+DACT_CODE = {None: DACT_NONE, "linear": DACT_NONE, "relu": DACT_RELU, "sigmoid": DACT_SIGMOID, "tanh": DACT_TANH,
+             "dice": DACT_DICE, "prelu": DACT_PRELU}
+
+
+def din_prepare(W1, b1, D, H):
+    """W1 [3D+D*D, H], b1 [H] -> Wcat [D, D*H+H], Wkd [D,H], bext [D*H+H]."""
+    dev = W1.device
+    N = D * H + H
+    Wcat = torch.empty((D, N), dtype=torch.float32, device=dev)
+    Wkd = torch.empty((D, H), dtype=torch.float32, device=dev)
+    bext = torch.empty(N, dtype=torch.float32, device=dev)
+    check(lib.rec_din_prepare_f32(_ptr(_f32(W1, "W1")), _ptr(_f32(b1, "b1")), D, H, _ptr(Wcat), _ptr(Wkd), _ptr(bext),
+                                  _stream()), "rec_din_prepare_f32")
+    return Wcat, Wkd, bext
+
+
+def din_prepare_bwd(gWcat, gWkd, D, H):
+    gW1 = torch.empty((3 * D + D * D, H), dtype=torch.float32, device=gWcat.device)
+    check(lib.rec_din_prepare_bwd_f32(_ptr(_f32(gWcat, "gWcat")), _ptr(_f32(gWkd, "gWkd")), D, H, _ptr(gW1), _stream()),
+          "rec_din_prepare_bwd_f32")
+    return gW1
+
+
+def _attn_common(embed, series, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index, mask_valid):
+    _table(embed, "embed"); _i64(series, "series")
+    V, E = embed.shape
+    B, T, Cn = series.shape
+    H = Wkd.shape[1]
+    return [_ptr(embed), embed.stride(0), V, E, Cn, _ptr(series), B, T, _ptr(_f32(Mext, "Mext")), _ptr(_f32(Wkd, "Wkd")),
+            H, act, _ptr(alpha), _ptr(mean), _ptr(var), _ptr(_f32(w2, "w2")), _ptr(_f32(b2, "b2")), int(padding_index),
+            int(bool(mask_valid))], (B, T, Cn * E, H)
+
+
+def din_attn_fwd(embed, series, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index, mask_valid, oob=None):
+    args, (B, T, D, H) = _attn_common(embed, series, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index,
+                                      mask_valid)
+    scores = torch.empty((B, T), dtype=torch.float32, device=embed.device)
+    pooled = torch.empty((B, D), dtype=torch.float32, device=embed.device)
+    check(lib.rec_din_attn_fwd_f32(*args, _ptr(scores), _ptr(pooled), _ptr(oob), _stream()), "rec_din_attn_fwd_f32")
+    return scores, pooled
+
+
+def din_attn_bwd(embed, series, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index, mask_valid, scores, gpooled):
+    args, (B, T, D, H) = _attn_common(embed, series, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index,
+                                      mask_valid)
+    dev = embed.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    gkeys = torch.empty((B, T, D), **f32)
+    gMext = torch.empty((B, D * H + H), **f32)
+    gw2p = torch.empty((B, H), **f32)
+    galphap = torch.empty((B, H), **f32)
+    gb2p = torch.empty((B, 1), **f32)
+    check(lib.rec_din_attn_bwd_f32(*args, _ptr(_f32(scores, "scores")), _ptr(_f32(gpooled, "gpooled")), _ptr(gkeys),
+                                   _ptr(gMext), _ptr(gw2p), _ptr(galphap), _ptr(gb2p), _stream()),
+          "rec_din_attn_bwd_f32")
+    return gkeys, gMext, gw2p, galphap, gb2p
+
+
+def feat_act_fwd(kind, x, alpha=None, mean=None, var=None):
+    M, N = x.shape
+    y = torch.empty_like(x)
+    check(lib.rec_feat_act_fwd_f32(kind, _ptr(_f32(x, "x")), _ptr(alpha), _ptr(mean), _ptr(var), _ptr(y), M, N,
+                                   _stream()), "rec_feat_act_fwd_f32")
+    return y
+
+
+def feat_act_bwd(kind, x, gy, alpha=None, mean=None, var=None, want_alpha=False):
+    M, N = x.shape
+    gx = torch.empty_like(x)
+    ga = torch.empty_like(x) if want_alpha else None
+    check(lib.rec_feat_act_bwd_f32(kind, _ptr(x), _ptr(_f32(gy, "gy")), _ptr(alpha), _ptr(mean), _ptr(var), _ptr(gx),
+                                   _ptr(ga), M, N, _stream()), "rec_feat_act_bwd_f32")
+    return gx, ga
+
+
+def layernorm_fwd(x, gamma, beta):
+    M, N = x.shape
+    y, xhat = torch.empty_like(x), torch.empty_like(x)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    check(lib.rec_layernorm_fwd_f32(_ptr(_f32(x, "x")), _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")), M, N,
+                                    _ptr(y), _ptr(xhat), _ptr(rstd), _stream()), "rec_layernorm_fwd_f32")
+    return y, xhat, rstd
+
+
+def layernorm_bwd(gy, xhat, rstd, gamma):
+    M, N = gy.shape
+    gx, gg = torch.empty_like(gy), torch.empty_like(gy)
+    check(lib.rec_layernorm_bwd_f32(_ptr(_f32(gy, "gy")), _ptr(xhat), _ptr(rstd), _ptr(gamma), M, N, _ptr(gx), _ptr(gg),
+                                    _stream()), "rec_layernorm_bwd_f32")
+    return gx, gg
+
+
+def softmax_fwd(x):
+    M, N = x.shape
+    y = torch.empty_like(x)
+    check(lib.rec_softmax_fwd_f32(_ptr(_f32(x, "x")), M, N, _ptr(y), _stream()), "rec_softmax_fwd_f32")
+    return y
+
+
+def softmax_bwd(y, gy):
+    M, N = y.shape
+    gx = torch.empty_like(y)
+    check(lib.rec_softmax_bwd_f32(_ptr(y), _ptr(_f32(gy, "gy")), M, N, _ptr(gx), _stream()), "rec_softmax_bwd_f32")
+    return gx

@@ -95,8 +95,9 @@ int rec_dedup_plan_i64(const int64_t* ids, int64_t n, int64_t V, int64_t* uniq_i
 /* out[u,:] = sum over s in [seg_start[u], seg_start[u+1]) of vals[perm[s] / row_div, :]   for u in [0,n).
  * row_div = 1 for per-lookup values; row_div = F broadcasts a per-example value (the w table, whose
  * per-lookup gradient is gz[b]). */
+size_t rec_segment_sum_workspace_bytes(int64_t n, int E);
 int rec_segment_sum_f32(const float* vals, int E, const int32_t* perm, const int32_t* seg_start, int64_t n,
-                        int32_t row_div, float* out, void* stream);
+                        int32_t row_div, float* out, float* workspace, void* stream);
 
 /* ---- K5/K6  dense: C[M,N] = epi(op(A).op(B)), fp32-exact MFMA (v_mfma_f32_32x32x2_f32).
  * op(A) is [M,K]: transA=0 -> A stored [M,K] (lda), transA=1 -> A stored [K,M].  op(B) is [K,N]:
@@ -177,6 +178,49 @@ int rec_shard_bucketize_i64(const int64_t* ids, int64_t n, int64_t rows_per_shar
 /* out[perm[i], :] = in[i, :]   (inverse permutation of received rows) and its transpose */
 int rec_permute_rows_f32(const float* in, const int64_t* perm, int64_t n, int E, int scatter, float* out,
                          void* stream);
+
+/* ---- K8/K9  DIN ActivationUnit + masked sum pooling (5.DIN/CustomLayers.py:163-180, 256-282), factorised:
+ *   pre[b,t,:] = c_b + k_t . Eff_b,  Eff_b = (W_k - W_d) + M_b,  M_b[i,o] = sum_j q_j W_o[i,j,o],
+ *   c_b = q (W_q + W_d) + b1;  score = act(pre) . w2 + b2;  pooled[b,:] = sum_t mask[b,t] * score[b,t] * k_t.
+ * D = E*C (C item features), H = hidden width (36 in the reference), W1 = the Dense(H) kernel [3D + D*D, H].
+ * activation kinds for per-feature activations (alpha/mean/var are [H] device vectors; unused ones may be NULL): */
+enum { REC_DACT_NONE = 0, REC_DACT_RELU = 1, REC_DACT_SIGMOID = 2, REC_DACT_TANH = 3,
+       REC_DACT_DICE = 4,   /* Dice, BN(center=False, scale=False) with moving statistics (5.DIN/CustomLayers.py:183-196) */
+       REC_DACT_PRELU = 5 };
+/* W1, b1 -> Wcat [D, D*H + H] = [Wo_r | W_q + W_d], Wkd [D,H] = W_k - W_d, bext [D*H + H] = [0 | b1]; then
+ * Mext = q . Wcat + bext is ONE rec_gemm_f32 per batch.  prepare_bwd maps (gWcat, gWkd) back onto gW1. */
+int rec_din_prepare_f32(const float* W1, const float* b1, int D, int H, float* Wcat, float* Wkd, float* bext,
+                        void* stream);
+int rec_din_prepare_bwd_f32(const float* gWcat, const float* gWkd, int D, int H, float* gW1, void* stream);
+/* series: int64 [B,T,C] (the tf.stack(axis=2) of the behaviour series, :258); key k_t = concat_r embed[series[b,t,r]].
+ * mask: reference behaviour (mask_valid = 0) keeps PADDED positions (series[b,t,0] == padding_index, :256,277-278);
+ * mask_valid = 1 is the intended form.  scores [B,T] are the raw (unmasked) scores; pooled [B,D]. */
+int rec_din_attn_fwd_f32(const float* embed, int64_t ld, int64_t V, int E, int C, const int64_t* series, int64_t B,
+                         int T, const float* Mext, const float* Wkd, int H, int act, const float* alpha,
+                         const float* mean, const float* var, const float* w2, const float* b2,
+                         int64_t padding_index, int mask_valid, float* scores, float* pooled, int* oob_flag,
+                         void* stream);
+/* backward: gkeys [B,T,D] (IndexedSlices values of the series lookups), gMext [B, D*H+H], and per-example partials
+ * gw2p [B,H], galphap [B,H], gb2p [B] (column sums of these are the parameter gradients). */
+int rec_din_attn_bwd_f32(const float* embed, int64_t ld, int64_t V, int E, int C, const int64_t* series, int64_t B,
+                         int T, const float* Mext, const float* Wkd, int H, int act, const float* alpha,
+                         const float* mean, const float* var, const float* w2, const float* b2,
+                         int64_t padding_index, int mask_valid, const float* scores, const float* gpooled,
+                         float* gkeys, float* gMext, float* gw2p, float* galphap, float* gb2p, void* stream);
+
+/* ---- rows of DIN's final MLP (make_mlp_layer, 5.DIN/CustomLayers.py:142-160) */
+/* y = act(x) on [M,N] with per-feature parameters; bwd also returns gy * dy/dalpha per element (column-sum it) */
+int rec_feat_act_fwd_f32(int kind, const float* x, const float* alpha, const float* mean, const float* var, float* y,
+                         int64_t M, int N, void* stream);
+int rec_feat_act_bwd_f32(int kind, const float* x, const float* gy, const float* alpha, const float* mean,
+                         const float* var, float* gx, float* ga_elem, int64_t M, int N, void* stream);
+/* keras LayerNormalization (epsilon 1e-3): y = xhat*gamma + beta; saves xhat [M,N] and rstd [M] */
+int rec_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, int64_t M, int N, float* y,
+                          float* xhat, float* rstd, void* stream);
+int rec_layernorm_bwd_f32(const float* gy, const float* xhat, const float* rstd, const float* gamma, int64_t M, int N,
+                          float* gx, float* gg_elem, void* stream);
+int rec_softmax_fwd_f32(const float* x, int64_t M, int N, float* y, void* stream);
+int rec_softmax_bwd_f32(const float* y, const float* gy, int64_t M, int N, float* gx, void* stream);
 
 #ifdef __cplusplus
 }
