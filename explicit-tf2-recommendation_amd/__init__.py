@@ -10,5 +10,10 @@ from . import _lib  # noqa: F401  (raises if the HIP library is missing: there i
 from . import ops  # noqa: F401
 from . import functional  # noqa: F401
 from . import layers  # noqa: F401
+from . import data  # noqa: F401
+from . import engine  # noqa: F401
+from . import sharded  # noqa: F401
+from . import model_manager  # noqa: F401
+from .model_manager import ModelManager  # noqa: F401
 
-__all__ = ["ops", "functional", "layers"]
+__all__ = ["ops", "functional", "layers", "data", "engine", "sharded", "model_manager", "ModelManager"]
