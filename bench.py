@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=CFG["batch"])
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly (no hipGraph replay)")
+    ap.add_argument("--generic", action="store_true", help="use the generic ~35-kernel step instead of the fused one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--adam-steps", type=int, default=10, help="extra: full train steps with reference-exact Adam")
@@ -122,7 +123,10 @@ def main():
     gen = data.SyntheticGenerator(names, V, dist=args.dist, seed=rank)
     n_batches = 4
     batches = [data.to_device(gen.batch(B)) for _ in range(n_batches)]
-    step = engine.DeepFMTrainStep(layer, B, optimizer=None, use_graph=not args.no_graph)
+    if args.generic:
+        step = engine.DeepFMTrainStep(layer, B, optimizer=None, use_graph=not args.no_graph)
+    else:   # 4 launches per step: fused fwd+bwd, reduction, per-column LDS sort (second stream), segment sums
+        step = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, optimizer=None, use_graph=not args.no_graph)
 
     def barrier():
         if world > 1:
@@ -141,8 +145,8 @@ def main():
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if int(step.oob.item()) != 0:
-        raise SystemExit("out-of-range id seen by the gather kernel")
+    if int(step.oob.item()) != 0 or (hasattr(step, "bad_ids") and int(step.bad_ids.item()) != 0):
+        raise SystemExit("out-of-range id seen by the gather / sort kernels")
     loss = float(step.loss.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
@@ -150,7 +154,7 @@ def main():
     # ---- roofline of the dominant HBM kernel: the fused embedding gather + FM forward ------------------
     # algorithmic bytes per launch: B*F*(8 + E*4 + 4) + B*4 = ids + embed rows + w scalars + logit
     algo_bytes = B * F * (8 + E * 4 + 4) + B * 4
-    X = step.X
+    X = ops.index_pack([batches[0][k] for k in names])
     emb, w, bias = layer.embed.embeddings, layer.w.embeddings, layer.bias
     reps = 100
     import ctypes as C
@@ -185,7 +189,8 @@ def main():
 
     extra = {}
     if args.adam_steps > 0 and rank == 0:
-        st2 = engine.DeepFMTrainStep(layer, B, optimizer="keras_adam", lr=1e-3, use_graph=False)
+        st2 = (engine.DeepFMTrainStep(layer, B, optimizer="keras_adam", lr=1e-3, use_graph=False) if args.generic else
+               engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, optimizer="keras_adam", lr=1e-3, use_graph=False))
         for i in range(2):
             st2(batches[i % n_batches])
         torch.cuda.synchronize()
@@ -206,7 +211,7 @@ def main():
                "config": {"workload": CFG["workload"], "vocab": V, "fields": F, "embedding_dims": E,
                           "mlp_dims": CFG["mlp_dims"], "batch_per_gpu": B, "id_distribution": args.dist,
                           "parallelism": "1 process per GPU, independent replicas" if world > 1 else "single GPU",
-                          "hipgraph": not args.no_graph},
+                          "hipgraph": not args.no_graph, "step": "generic" if args.generic else "fused-4-launch"},
                "roofline": roofline, "loss": loss}
         out.update(extra)
         if not args.no_cpu_baseline and world == 1:

@@ -238,3 +238,161 @@ class DeepFMTrainStep:
         out["embed.embeddings"] = (self.uniq_ids, self.g_embed_rows, self.n_uniq)
         out["w.embeddings"] = (self.uniq_ids, self.g_w_rows, self.n_uniq)
         return out
+
+
+def _bits(n):
+    b = 1
+    while (1 << b) < n:
+        b += 1
+    return b
+
+
+class DeepFMFusedStep:
+    """The same train_loop iteration as DeepFMTrainStep in FOUR launches (csrc/deepfm_fused.hip): the fused
+    forward+backward kernel and its fixed-order reduction on one stream, the per-column LDS sort of the
+    de-duplication plan on a second stream (it depends only on the ids), then the segment sums.
+
+    Requirements (checked; otherwise use DeepFMTrainStep): embedding_dims 16, mlp_dims [32,8], fused table layout,
+    F <= 28, B <= 16384, and the DataGenerator id-space contract -- ``field_offsets[f]``/``field_dims[f]`` =
+    ``data_info.json``'s offsets and dims (2.FM/DataGenerator.py:126-134); an id outside its field's range sets
+    ``self.bad_ids`` (checked by ``check_flags()``).
+    """
+
+    def __init__(self, layer, batch_size, field_dims, field_offsets, optimizer=None, lr=1e-3, use_graph=True):
+        self.layer = layer
+        self.B = B = int(batch_size)
+        self.F = F = len(layer.feature_names)
+        emb, w = layer.embed.embeddings, layer.w.embeddings
+        self.V, self.E = emb.shape
+        if self.E != 16 or list(layer.mlp_dims) != [32, 8]:
+            raise NotImplementedError("the fused step covers embedding_dims=16, mlp_dims=[32,8]")
+        if emb.stride(0) != 32 or w.stride(0) != 32 or w.data_ptr() != emb.data_ptr() + 64:
+            raise NotImplementedError("the fused step needs the fused [embed|w|pad] table layout (layer.cuda())")
+        if F > 28 or B > 16384 or len(field_dims) != F or len(field_offsets) != F:
+            raise NotImplementedError("fused step: F <= 28, B <= 16384, one (dim, offset) per feature")
+        if any(field_offsets[i] >= field_offsets[i + 1] for i in range(F - 1)):
+            raise ValueError("field offsets must be ascending (DataGenerator contract)")
+        self.max_key = max(int(d) for d in field_dims) - 1
+        if _bits(self.max_key + 1) + _bits(B) > 32 or ((self.max_key << _bits(B)) | (B - 1)) >= 0xFFFFFFFF:
+            raise NotImplementedError("field too wide for the 32-bit sort words at this batch size")
+        dev = emb.device
+        self.dev = dev
+        self.optimizer, self.lr, self.use_graph, self.t = optimizer, lr, use_graph, 0
+        f32 = dict(dtype=torch.float32, device=dev)
+        n, D = B * F, F * 16
+        self.col_lo = torch.tensor([int(o) for o in field_offsets], dtype=torch.int64, device=dev)
+        self.gz = torch.empty(B, **f32)
+        self.vals = torch.empty((n, 16), **f32)
+        self.loss = torch.empty(1, **f32)
+        self.oob = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.bad_ids = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.g = {
+            "MLP_layer1.kernel_0": torch.empty((D, 32), **f32), "MLP_layer1.bias_0": torch.empty(32, **f32),
+            "MLP_layer1.kernel_1": torch.empty((32, 8), **f32), "MLP_layer1.bias_1": torch.empty(8, **f32),
+            "MLP_layer2.kernel_0": torch.empty((8, 1), **f32), "MLP_layer2.bias_0": torch.empty(1, **f32),
+            "bias": torch.empty(1, **f32),
+        }
+        self.ws = torch.empty(lib.rec_deepfm_fused_workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+        self.perm = torch.empty((F, B), dtype=torch.int32, device=dev)
+        self.col_uid = torch.empty((F, B), dtype=torch.int64, device=dev)
+        self.col_seg = torch.empty((F, B + 1), dtype=torch.int32, device=dev)
+        self.col_nu = torch.zeros(F, dtype=torch.int32, device=dev)
+        self.uniq_ids = torch.empty(n, dtype=torch.int64, device=dev)
+        self.g_embed_rows = torch.empty((n, 16), **f32)
+        self.g_w_rows = torch.empty((n, 1), **f32)
+        self.n_uniq = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.sort_ws = torch.empty(lib.rec_colsort_workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+        self.side_stream = torch.cuda.Stream(device=dev)
+        if optimizer is not None:
+            self.state = {name: (torch.zeros(p.shape, **f32), torch.zeros(p.shape, **f32))
+                          for name, p in layer.named_parameters()}
+            self.side_e = torch.empty((n, 3, 16), **f32)
+            self.side_w = torch.empty((n, 3, 1), **f32)
+        self._graphs = {}
+
+    def _enqueue(self, cols, label, t):
+        L = self.layer
+        F, B, V = self.F, self.B, self.V
+        arr = (C.c_void_p * F)(*[c.data_ptr() for c in cols])
+        main = torch.cuda.current_stream()
+        side = self.side_stream
+        side.wait_stream(main)                                   # fork: the sort only needs the ids
+        with torch.cuda.stream(side):
+            check(lib.rec_colsort_plan_i64(arr, F, B, V, _p(self.col_lo), self.max_key, _p(self.perm),
+                                           _p(self.col_uid), _p(self.col_seg), _p(self.col_nu), _p(self.bad_ids),
+                                           _p(self.sort_ws), C.c_void_p(side.cuda_stream)), "rec_colsort_plan_i64")
+        st = C.c_void_p(main.cuda_stream)
+        g = self.g
+        emb = L.embed.embeddings
+        check(lib.rec_deepfm_fused_fwd_bwd_f32(
+            _p(emb), emb.stride(0), V, arr, F, B, _p(L.bias), _p(L.MLP_layer1.kernel_0), _p(L.MLP_layer1.bias_0),
+            _p(L.MLP_layer1.kernel_1), _p(L.MLP_layer1.bias_1), _p(L.MLP_layer2.kernel_0), _p(L.MLP_layer2.bias_0),
+            _p(label), _p(self.gz), _p(self.vals), None, _p(g["MLP_layer1.kernel_0"]), _p(g["MLP_layer1.bias_0"]),
+            _p(g["MLP_layer1.kernel_1"]), _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]),
+            _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(self.loss), _p(self.oob), _p(self.ws), st),
+            "rec_deepfm_fused_fwd_bwd_f32")
+        main.wait_stream(side)                                   # join
+        check(lib.rec_colseg_sum_f32(_p(self.vals), _p(self.gz), _p(self.perm), _p(self.col_uid), _p(self.col_seg),
+                                     _p(self.col_nu), B, F, _p(self.uniq_ids), _p(self.g_embed_rows),
+                                     _p(self.g_w_rows), _p(self.n_uniq), st), "rec_colseg_sum_f32")
+        if self.optimizer is not None:
+            self._optimizer(t, st)
+
+    def _optimizer(self, t, st):
+        lr, b1, b2, eps = self.lr, 0.9, 0.999, 1e-7
+        params = dict(self.layer.named_parameters())
+        for name, grad in self.g.items():
+            m, v = self.state[name]
+            check(lib.rec_adam_dense_f32(_p(params[name]), _p(m), _p(v), _p(grad), grad.numel(), t, lr, b1, b2, eps, st),
+                  "rec_adam_dense_f32")
+        n = self.B * self.F
+        for name, rows, side, E in (("embed.embeddings", self.g_embed_rows, self.side_e, 16),
+                                    ("w.embeddings", self.g_w_rows, self.side_w, 1)):
+            m, v = self.state[name]
+            p = params[name]
+            if self.optimizer == "keras_adam":
+                check(lib.rec_adam_sparse_keras_f32(_p(p), p.stride(0), _p(m), _p(v), self.V, E, _p(self.uniq_ids),
+                                                    _p(rows), _p(self.n_uniq), n, _p(side), t, lr, b1, b2, eps, st),
+                      "rec_adam_sparse_keras_f32")
+            else:
+                check(lib.rec_adam_rows_f32(_p(p), p.stride(0), _p(m), _p(v), self.V, E, _p(self.uniq_ids), _p(rows),
+                                            _p(self.n_uniq), n, t, lr, b1, b2, eps, st), "rec_adam_rows_f32")
+
+    def __call__(self, inputs, label_name="label"):
+        cols = []
+        for name in self.layer.feature_names:
+            c = inputs[name]
+            if c.dtype != torch.int64 or not c.is_cuda or c.numel() != self.B or not c.is_contiguous():
+                raise ValueError("feature %r must be a contiguous int64 CUDA tensor with %d ids" % (name, self.B))
+            cols.append(c)
+        y = inputs[label_name]
+        if y.dtype != torch.float32 or not y.is_cuda or y.numel() != self.B or not y.is_contiguous():
+            raise ValueError("label must be a contiguous float32 CUDA tensor with %d entries" % self.B)
+        self.t += 1
+        if not self.use_graph or self.optimizer is not None:
+            self._enqueue(cols, y, self.t)
+            return self.loss
+        key = tuple(c.data_ptr() for c in cols) + (y.data_ptr(),)
+        ent = self._graphs.get(key)
+        if ent is None:
+            self._enqueue(cols, y, self.t)                       # warm-up (also sets the kernel attributes)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._enqueue(cols, y, self.t)
+            ent = (g, cols, y)
+            self._graphs[key] = ent
+        ent[0].replay()
+        return self.loss
+
+    def check_flags(self):
+        if int(self.oob.item()) != 0:
+            raise IndexError("embedding id out of range [0, feature_dims)")
+        if int(self.bad_ids.item()) != 0:
+            raise ValueError("an id lies outside its field's [offset, offset+dim) range (DataGenerator contract)")
+
+    def gradients(self):
+        out = dict(self.g)
+        out["embed.embeddings"] = (self.uniq_ids, self.g_embed_rows, self.n_uniq)
+        out["w.embeddings"] = (self.uniq_ids, self.g_w_rows, self.n_uniq)
+        return out

@@ -179,6 +179,33 @@ int rec_shard_bucketize_i64(const int64_t* ids, int64_t n, int64_t rows_per_shar
 int rec_permute_rows_f32(const float* in, const int64_t* perm, int64_t n, int E, int scatter, float* out,
                          void* stream);
 
+/* ---- Fused DeepFM train step (2.FM/CustomLayers.py:279-308 under 2.FM/ModelManager.py:171-177) for the reference's
+ * default head (embedding_dims 16, mlp_dims [32,8]) on the fused 128-byte row layout (ld = 32): index assembly from the
+ * F feature columns, gather, FM, MLP (fp32 MFMA), sigmoid, Keras BCE and the whole backward in ONE kernel + one
+ * fixed-order reduction.  Outputs: gz [B] = dL/dz, vals [B*F,16] = IndexedSlices values of `embed` (the values of `w`
+ * are gz[b]), dense gradients, loss (device scalar, mean BCE), prob [B] (optional).  F <= 28.
+ * workspace: rec_deepfm_fused_workspace_bytes(B, F). */
+size_t rec_deepfm_fused_workspace_bytes(int64_t B, int F);
+int rec_deepfm_fused_fwd_bwd_f32(const float* table, int64_t ld, int64_t V, const int64_t* const* cols_host, int F,
+                                 int64_t B, const float* bias, const float* K0, const float* b0, const float* K1,
+                                 const float* b1, const float* K2, const float* b2, const float* label, float* gz,
+                                 float* vals, float* prob, float* dK0, float* db0, float* dK1, float* db1, float* dK2,
+                                 float* db2, float* dbias, float* loss, int* oob_flag, void* workspace, void* stream);
+/* De-duplication plan that uses the DataGenerator contract (2.FM/DataGenerator.py:76-88): column f only holds ids of
+ * [col_lo[f], col_lo[f] + 2^key_bits) and columns are given in ascending range order, so duplicates occur only inside
+ * a column and each column (B <= 16384 ids; max_key = largest id - col_lo over all columns, bits(max_key) +
+ * ceil(log2 B) <= 32) is sorted on its own (chunk sort + rank merge + run detection).
+ * perm [F,B], col_uid [F,B], col_seg [F,B+1], col_nu [F]; an id outside its column's range sets *bad_flag. */
+size_t rec_colsort_workspace_bytes(int64_t B, int F);
+int rec_colsort_plan_i64(const int64_t* const* cols_host, int F, int64_t B, int64_t V, const int64_t* col_lo,
+                         int64_t max_key, int32_t* perm, int64_t* col_uid, int32_t* col_seg, int32_t* col_nu,
+                         int* bad_flag, void* workspace, void* stream);
+/* segment sums of vals [B*F,16] (embed) and gz [B] (w) over that plan + compaction to the global ascending list:
+ * uniq_ids [B*F], g_embed_rows [B*F,16], g_w_rows [B*F], n_uniq; the tail is padded like rec_dedup_plan_i64's. */
+int rec_colseg_sum_f32(const float* vals, const float* gz, const int32_t* perm, const int64_t* col_uid,
+                       const int32_t* col_seg, const int32_t* col_nu, int64_t B, int F, int64_t* uniq_ids,
+                       float* g_embed_rows, float* g_w_rows, int64_t* n_uniq, void* stream);
+
 /* ---- K8/K9  DIN ActivationUnit + masked sum pooling (5.DIN/CustomLayers.py:163-180, 256-282), factorised:
  *   pre[b,t,:] = c_b + k_t . Eff_b,  Eff_b = (W_k - W_d) + M_b,  M_b[i,o] = sum_j q_j W_o[i,j,o],
  *   c_b = q (W_q + W_d) + b1;  score = act(pre) . w2 + b2;  pooled[b,:] = sum_t mask[b,t] * score[b,t] * k_t.

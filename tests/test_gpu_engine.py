@@ -43,9 +43,12 @@ def oracle_grads(layer, names, batch):
     return loss.item(), {k: v.grad.numpy() for k, v in pr.items()}
 
 
-def close(a, b, tol=2e-5):
+def close(a, b, tol=2e-5, floor=1e-3):
+    """max-abs error <= tol * max|reference|.  A one-element gradient (the FM bias, the last bias) is a sum of B
+    signed terms of size ~1/B that can cancel to ~0, so the scale never drops below `floor` (i.e. an absolute 2e-8:
+    a few fp32 ulps of the terms that were added)."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    return np.abs(a - b).max() <= tol * max(1e-30, np.abs(b).max())
+    return np.abs(a - b).max() <= tol * max(floor, np.abs(b).max())
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
@@ -133,3 +136,100 @@ def test_deepfm_train_steps_with_adam(opt):
         step(data.to_device(batch))
         for k, q in layer.named_parameters():
             assert np.abs(q.detach().cpu().numpy() - params[k]).max() <= 5e-5, (k, t)
+
+
+# ------------------------------------------------------------------------------------------------
+# the 4-launch fused step (csrc/deepfm_fused.hip)
+# ------------------------------------------------------------------------------------------------
+def make16(B, F, V, seed, dist):
+    from explicit_tf2_recommendation_amd import layers, data
+    names = ["f%d" % i for i in range(F)]
+    layers.set_init_seed(seed)
+    layer = layers.DeepFMRankingLayer(feature_names=names, feature_dims=V, embedding_dims=16, mlp_dims=[32, 8]).cuda()
+    with torch.no_grad():
+        for n, p in layer.named_parameters():
+            if "bias_" in n:
+                p.uniform_(-0.1, 0.1)
+        # keep |z| moderate (test data keeps |z| < 15): with 26 fields a 6x table saturates the
+        # sigmoid and fp32 p*(1-p) -- in TF as much as here -- drifts from the fp64 oracle by more than the tolerance
+        layer.embed.embeddings.mul_(6.0 if F <= 8 else 2.0)
+    gen = data.SyntheticGenerator(names, V, dist=dist, seed=seed)
+    return layer, names, gen
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("B,F,V,dist", [(256, 5, 5547, "zipf"), (8192, 26, 1000000, "uniform"), (1000, 3, 300, "zipf"),
+                                         (2048, 26, 200000, "zipf"), (33, 7, 4000, "uniform")])
+def test_fused_step_matches_oracle(use_graph, B, F, V, dist):
+    from explicit_tf2_recommendation_amd import engine, data
+    layer, names, gen = make16(B, F, V, 11, dist)
+    step = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, use_graph=use_graph)
+    for it in range(2):
+        batch = gen.batch(B)
+        dbatch = data.to_device(batch)
+        loss = step(dbatch)
+        if use_graph:
+            loss = step(dbatch)
+        step.check_flags()
+        ref_loss, ref = oracle_grads(layer, names, batch)
+        assert abs(loss.item() - ref_loss) <= 1e-5 * max(1, abs(ref_loss))
+        g = step.gradients()
+        for name in ("MLP_layer1.kernel_0", "MLP_layer1.bias_0", "MLP_layer1.kernel_1", "MLP_layer1.bias_1",
+                     "MLP_layer2.kernel_0", "MLP_layer2.bias_0", "bias"):
+            assert close(g[name].cpu().numpy(), ref[name]), name
+        touched = np.unique(L.index_assemble(batch, names))
+        for name in ("embed.embeddings", "w.embeddings"):
+            ids, rows, nu = g[name]
+            nu = int(nu.item())
+            assert np.array_equal(ids.cpu().numpy()[:nu], touched)            # bit exact, ascending
+            assert close(rows.cpu().numpy()[:nu], ref[name][touched]), name
+            assert np.all(rows.cpu().numpy()[nu:] == 0) and np.all(ids.cpu().numpy()[nu:] == touched[0])
+
+
+def test_fused_step_equals_generic_step_and_is_deterministic():
+    from explicit_tf2_recommendation_amd import engine, data
+    B, F, V = 4096, 26, 500000
+    layer, names, gen = make16(B, F, V, 13, "zipf")
+    batch = data.to_device(gen.batch(B))
+    fused = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, use_graph=False)
+    generic = engine.DeepFMTrainStep(layer, B, use_graph=False)
+    l1, l2 = fused(batch).item(), generic(batch).item()
+    assert abs(l1 - l2) <= 1e-6
+    g1, g2 = fused.gradients(), generic.gradients()
+    nu = int(g1["embed.embeddings"][2].item())
+    assert nu == int(g2["embed.embeddings"][2].item())
+    assert torch.equal(g1["embed.embeddings"][0][:nu], g2["embed.embeddings"][0][:nu])
+    assert close(g1["embed.embeddings"][1][:nu].cpu().numpy(), g2["embed.embeddings"][1][:nu].cpu().numpy(), 1e-5)
+    assert close(g1["MLP_layer1.kernel_0"].cpu().numpy(), g2["MLP_layer1.kernel_0"].cpu().numpy(), 1e-5)
+    snap = {k: (v[1].clone() if isinstance(v, tuple) else v.clone()) for k, v in g1.items()}
+    fused(batch)
+    for k, v in fused.gradients().items():
+        assert torch.equal(v[1] if isinstance(v, tuple) else v, snap[k]), k       # run-to-run bit identical
+
+
+def test_fused_step_flags_contract_violation():
+    from explicit_tf2_recommendation_amd import engine, data
+    B, F, V = 256, 5, 5547
+    layer, names, gen = make16(B, F, V, 17, "uniform")
+    step = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, use_graph=False)
+    batch = gen.batch(B)
+    batch[names[3]][7, 0] = gen.offsets[1]              # an id of field 1 in the column of field 3
+    step(data.to_device(batch))
+    with pytest.raises(ValueError):
+        step.check_flags()
+
+
+def test_fused_step_with_keras_adam_matches_generic():
+    from explicit_tf2_recommendation_amd import engine, data
+    B, F, V = 512, 6, 3000
+    la, names, gen = make16(B, F, V, 19, "zipf")
+    lb, _, _ = make16(B, F, V, 19, "zipf")
+    lb.load_state_dict(la.state_dict())                  # the random biases of make16 differ between the two
+    a = engine.DeepFMFusedStep(la, B, gen.dims, gen.offsets, optimizer="keras_adam", lr=0.01, use_graph=False)
+    b = engine.DeepFMTrainStep(lb, B, optimizer="keras_adam", lr=0.01, use_graph=False)
+    for _ in range(3):
+        batch = data.to_device(gen.batch(B))
+        a(batch)
+        b(batch)
+    for (k, p), (_, q) in zip(la.named_parameters(), lb.named_parameters()):
+        assert np.abs(p.detach().cpu().numpy() - q.detach().cpu().numpy()).max() <= 2e-5, k
