@@ -133,12 +133,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(max(args.warmup, n_batches)):        # warm-up also captures one graph per resident batch
-        step(batches[i % n_batches])
+    def run(i):
+        if args.generic:
+            step(batches[i % n_batches])
+        else:   # the next batch is announced: its de-duplication plan is built while this one is differentiated
+            step(batches[i % n_batches], next_inputs=batches[(i + 1) % n_batches])
+
+    nw = max(args.warmup, 2 * n_batches)                 # warm-up also captures the hipGraphs of the resident batches
+    nw += (-nw) % n_batches                              # ... and ends where the timed loop starts (batch 0)
+    for i in range(nw):
+        run(i)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(batches[i % n_batches])
+        run(i)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -151,15 +159,45 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
-    # ---- roofline of the dominant HBM kernel: the fused embedding gather + FM forward ------------------
-    # algorithmic bytes per launch: B*F*(8 + E*4 + 4) + B*4 = ids + embed rows + w scalars + logit
-    algo_bytes = B * F * (8 + E * 4 + 4) + B * 4
-    X = ops.index_pack([batches[0][k] for k in names])
-    emb, w, bias = layer.embed.embeddings, layer.w.embeddings, layer.bias
-    reps = 100
+    # ---- rooflines.  Average launch durations are measured live with HIP events around `reps` back-to-back launches
+    # replayed from a hipGraph (events and replay share torch's current stream); `traffic` = HBM bytes per launch
+    # from the PMC passes committed in profiles/r01_pmc_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE runs of
+    # this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
     import ctypes as C
     from explicit_tf2_recommendation_amd._lib import lib, check
     vp = lambda t: C.c_void_p(t.data_ptr())
+    pmc = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+    except (OSError, ValueError, KeyError):
+        pass
+
+    def timed(launch, reps):
+        launch(10)
+        torch.cuda.synchronize()
+        gg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gg):
+            launch(reps)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        gg.replay()
+        torch.cuda.synchronize()
+        ev0.record()
+        gg.replay()
+        ev1.record()
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) * 1e3 / reps
+
+    def roof(kernel, algo_bytes, us, traffic_keys, note):
+        achieved = algo_bytes / (us * 1e-6) / 1e9
+        tr = [pmc[k]["hbm_bytes_per_launch_corrected"] for k in traffic_keys if k in pmc]
+        return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": sum(tr) if len(tr) == len(traffic_keys) else None,
+                "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": us, "note": note}
+
+    # (1) standalone gather + FM forward (what FMRankingLayer's forward launches): ids + embed rows + w + logit
+    gather_bytes = B * F * (8 + E * 4 + 4) + B * 4
+    X = ops.index_pack([batches[0][k] for k in names])
+    emb, w, bias = layer.embed.embeddings, layer.w.embeddings, layer.bias
     zbuf = torch.empty(B, dtype=torch.float32, device="cuda")
 
     def launch_gather(n):
@@ -168,24 +206,37 @@ def main():
             check(lib.rec_emb_fm_fwd_f32(vp(emb), emb.stride(0), vp(w), w.stride(0), vp(bias), V, E, vp(X), B, F,
                                          vp(zbuf), None, None, None, None, st), "rec_emb_fm_fwd_f32")
 
-    launch_gather(10)
-    torch.cuda.synchronize()
-    gg = torch.cuda.CUDAGraph()       # back-to-back launches replayed from a hipGraph: no host gaps
-    with torch.cuda.graph(gg):
-        launch_gather(reps)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    gg.replay()
-    torch.cuda.synchronize()
-    ev0.record()                      # events and the replay share torch's current stream
-    gg.replay()
-    ev1.record()
-    torch.cuda.synchronize()
-    kern_us = ev0.elapsed_time(ev1) * 1e3 / reps
-    achieved = algo_bytes / (kern_us * 1e-6) / 1e9
-    roofline = {"bound": "hbm", "kernel": "emb_fm_fwd_vec_kernel<8,2,fused> (gather + FM over fused 128-B rows, no row write-back)",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": kern_us,
-                "timing": "HIP events around %d back-to-back launches on the launch stream" % reps}
+    roofline_gather = roof("emb_fm_fwd_vec_kernel<8,2,fused> (embedding gather + FM, fused 128-B rows)", gather_bytes,
+                           timed(launch_gather, 100), ["emb_fm_fwd_vec_kernel"],
+                           "a random row read costs one 128-B line whatever the row size (~50 G lines/s measured): "
+                           "the ceiling of this kernel is ~0.47 of the 8 TB/s spec in algorithmic bytes")
+    roofline = roofline_gather
+    if not args.generic:
+        # (2) the dominant kernel of the timed step: the fused forward+backward launch (+ its fixed-order reduction,
+        # same C call).  Algorithmic bytes: the gather above + labels + dL/dz + the IndexedSlices values it writes.
+        fused_bytes = gather_bytes + B * 4 + B * 4 + B * F * E * 4
+        fs = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, optimizer=None, use_graph=False)
+        cols = [batches[0][k] for k in names]
+        arr = (C.c_void_p * F)(*[c.data_ptr() for c in cols])
+        L, g = layer, fs.g
+
+        def launch_fused(n):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            for _ in range(n):
+                check(lib.rec_deepfm_fused_fwd_bwd_f32(
+                    vp(emb), emb.stride(0), V, arr, F, B, vp(L.bias), vp(L.MLP_layer1.kernel_0),
+                    vp(L.MLP_layer1.bias_0), vp(L.MLP_layer1.kernel_1), vp(L.MLP_layer1.bias_1),
+                    vp(L.MLP_layer2.kernel_0), vp(L.MLP_layer2.bias_0), vp(batches[0]["label"]), vp(fs.gz),
+                    vp(fs.vals), None, vp(g["MLP_layer1.kernel_0"]), vp(g["MLP_layer1.bias_0"]),
+                    vp(g["MLP_layer1.kernel_1"]), vp(g["MLP_layer1.bias_1"]), vp(g["MLP_layer2.kernel_0"]),
+                    vp(g["MLP_layer2.bias_0"]), vp(g["bias"]), vp(fs.loss), vp(fs.oob), vp(fs.ws), st),
+                    "rec_deepfm_fused_fwd_bwd_f32")
+
+        roofline = roof("deepfm_fwd_bwd_kernel + deepfm_reduce_kernel (one C-ABI call: gather, FM, MLP on fp32 MFMA, BCE, "
+                        "backward, IndexedSlices values)", fused_bytes, timed(launch_fused, 50),
+                        ["deepfm_fwd_bwd_kernel", "deepfm_reduce_kernel"],
+                        "latency/sync-bound at one 122-KB workgroup per CU; 0.65 GFLOP of fp32 MFMA per launch is ~1% of "
+                        "the matrix peak, so HBM is the binding roofline")
 
     extra = {}
     if args.adam_steps > 0 and rank == 0:
@@ -211,8 +262,10 @@ def main():
                "config": {"workload": CFG["workload"], "vocab": V, "fields": F, "embedding_dims": E,
                           "mlp_dims": CFG["mlp_dims"], "batch_per_gpu": B, "id_distribution": args.dist,
                           "parallelism": "1 process per GPU, independent replicas" if world > 1 else "single GPU",
-                          "hipgraph": not args.no_graph, "step": "generic" if args.generic else "fused-4-launch"},
-               "roofline": roofline, "loss": loss}
+                          "hipgraph": not args.no_graph, "step": "generic" if args.generic else
+                          "fused: fwd+bwd kernel, reduce, segment sums; de-duplication plan of batch k+1 (per-column "
+                          "sort, second stream) overlaps step k"},
+               "roofline": roofline, "roofline_gather": roofline_gather, "loss": loss}
         out.update(extra)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, names, args.cpu_seconds)

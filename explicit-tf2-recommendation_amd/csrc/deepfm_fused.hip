@@ -22,6 +22,7 @@
 // Everything is deterministic (no float atomics): per-workgroup partials + fixed-order reductions, stable sort keys.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -53,6 +54,7 @@ struct FusedArgs {
   float* dK0part;             // [nwg, F*16*32]
   float* small;               // [nwg, SMALL]
   int* oob;
+  int stop;                   // diagnostics only (REC_FUSED_STOP): leave after phase `stop` (0 = run everything)
 };
 
 __device__ __forceinline__ int xs_of(int F) { return F * E16 + 2; }
@@ -65,9 +67,12 @@ __global__ __launch_bounds__(256) void deepfm_fwd_bwd_kernel(Cols cols, FusedArg
   float* H1s = K0s + D * HS;             // [EX][HS]      relu(h1)
   float* DP1 = H1s + EX * HS;            // [EX][HS]      d pre-activation of layer 1
   float* Ss = DP1 + EX * HS;             // [EX][16]
-  float* Wl = Ss + EX * E16;             // [EX*F]        first-order weights of the lookups
-  int* ids = reinterpret_cast<int*>(Wl + EX * F);   // [EX*F]
-  float* h2s = reinterpret_cast<float*>(ids + EX * F);   // [EX][8]
+  // ids (P0-P1) and the first-order weights Wl (P1-P2) are dead before H1s / DP1 are first written (P3, P4):
+  // they share that region (2*EX*F <= 2*EX*HS for F <= 33), which keeps the workgroup at ~122 KB of LDS so that a
+  // 32-KB sort workgroup of the second stream can be co-resident on the CU
+  float* Wl = H1s;                       // [EX*F]
+  int* ids = reinterpret_cast<int*>(H1s + EX * F);   // [EX*F]
+  float* h2s = Ss + EX * E16;            // [EX][8]
   float* dp2s = h2s + EX * U2;           // [EX][8]
   float* zfm = dp2s + EX * U2;           // [EX]
   float* dzs = zfm + EX;                 // [EX]
@@ -81,53 +86,72 @@ __global__ __launch_bounds__(256) void deepfm_fwd_bwd_kernel(Cols cols, FusedArg
   const int64_t ex0 = (int64_t)blockIdx.x * EX;
   const int n_ex = (a.B - ex0 < EX) ? (int)(a.B - ex0) : EX;
 
-  // ---- P0: ids of the 32 examples from the F feature columns; weights of the dense head into LDS
+  // ---- P0: K0 (53 KB, the same for every workgroup) starts its trip from L2 into registers first, so that its
+  // latency hides behind the id fetch and the row gather; ids of the 32 examples from the F feature columns go to
+  // LDS as ids[f*32 + e] (one field per gather pass: no integer division anywhere)
+  constexpr int MAXK = 14;                                   // F <= 28: D*8/256 = F/2 float4 per thread
+  float4 kreg[MAXK];
+#pragma unroll
+  for (int q = 0; q < MAXK; ++q) {
+    int i = tid + q * 256;
+    kreg[q] = i < D * (U1 / 4) ? reinterpret_cast<const float4*>(a.K0)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   bool bad = false;
   for (int i = tid; i < EX * F; i += 256) {
-    int f = i / EX, e = i - f * EX;          // consecutive threads read consecutive examples of one column
+    int f = i >> 5, e = i & 31;              // consecutive threads read consecutive examples of one column
     int v = -1;
     if (e < n_ex) {
       int64_t id = cols.p[f][ex0 + e];
       if ((uint64_t)id < (uint64_t)a.V) v = (int)id; else bad = true;
     }
-    ids[e * F + f] = v;
+    ids[i] = v;
   }
   if (bad && a.oob) *a.oob = 1;
-  for (int i = tid; i < D * U1; i += 256) K0s[(i >> 5) * HS + (i & 31)] = a.K0[i];
   K1s[tid] = a.K1[tid];
   if (tid < U1) b0s[tid] = a.b0[tid];
   if (tid < U2) { b1s[tid] = a.b1[tid]; K2s[tid] = a.K2[tid]; }
   __syncthreads();
+  if (a.stop == 1) return;
 
-  // ---- P1: gather.  8 lanes x 16 B cover one 128-B row; 32 row slots per pass; all passes' loads issued first.
+  // ---- P1: gather.  8 lanes x 16 B cover one 128-B row; pass `it` = field it of the 32 examples; every pass's
+  // load is issued before anything is consumed (F independent 16-B loads in flight per lane)
   {
-    const int c = tid & 7, rs = tid >> 3;
-    constexpr int MAXP = 28;                 // F <= 28 passes (EX*F/32 = F)
+    const int c = tid & 7, e = tid >> 3;
+    constexpr int MAXP = 28;
     float4 v[MAXP];
 #pragma unroll
     for (int it = 0; it < MAXP; ++it) {
       v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (it < F && c <= 4) {
-        int id = ids[it * 32 + rs];          // row index rho = it*32 + rs = e*F + f
+        int id = ids[it * 32 + e];
         if (id >= 0) v[it] = *reinterpret_cast<const float4*>(a.table + (int64_t)id * LD + 4 * c);
       }
     }
+    // K0 registers -> LDS (rows of 33 floats) while the rows are in flight
+#pragma unroll
+    for (int q = 0; q < MAXK; ++q) {
+      int i = tid + q * 256;
+      if (i < D * (U1 / 4)) {
+        float* dst = K0s + (i >> 3) * HS + (i & 7) * 4;
+        dst[0] = kreg[q].x; dst[1] = kreg[q].y; dst[2] = kreg[q].z; dst[3] = kreg[q].w;
+      }
+    }
+    float* xrow = XT + e * XS + 4 * c;                       // 8-byte aligned only (XS even): two 8-byte stores
 #pragma unroll
     for (int it = 0; it < MAXP; ++it) {
       if (it < F) {
-        int rho = it * 32 + rs;
-        int e = rho / F, f = rho - e * F;
         if (c < 4) {
-          float* dst = XT + e * XS + f * E16 + 4 * c;     // 8-byte aligned only (XS even): two 8-byte stores
+          float* dst = xrow + it * E16;
           reinterpret_cast<float2*>(dst)[0] = make_float2(v[it].x, v[it].y);
           reinterpret_cast<float2*>(dst)[1] = make_float2(v[it].z, v[it].w);
         } else if (c == 4) {
-          Wl[rho] = v[it].x;
+          Wl[it * 32 + e] = v[it].x;
         }
       }
     }
   }
   __syncthreads();
+  if (a.stop == 2) return;
 
   // ---- P2: FM terms.  thread = (example e, dim pair d2)
   {
@@ -147,24 +171,44 @@ __global__ __launch_bounds__(256) void deepfm_fwd_bwd_kernel(Cols cols, FusedArg
     part += __shfl_xor(part, 4, 64);
     if (d2 == 0) {
       float first = 0.f;
-      for (int f = 0; f < F; ++f) first += Wl[e * F + f];
+      for (int f = 0; f < F; ++f) first += Wl[f * 32 + e];
       zfm[e] = a.bias[0] + first + 0.5f * part;
     }
   }
+  __syncthreads();                         // Wl / ids are dead from here on: their LDS becomes H1s / DP1
+  if (a.stop == 3) return;
 
   // ---- P3: h1 = relu(X . K0 + b0) on the matrix cores.  wave = (example tile et, unit half nh)
   const int et = wave >> 1, nh = wave & 1;
   const int l15 = lane & 15, g = lane >> 4;
   {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const float* ap = XT + (et * 16 + l15) * XS + g;
     const float* bp = K0s + g * HS + nh * 16 + l15;
-    for (int kk = 0; kk < D / 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * kk], bp[4 * kk * HS], acc, 0, 0, 0);
+    const int nk = D / 4;                                    // = 4F: a multiple of 4
+    float an[4], bn[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { an[u] = ap[4 * u]; bn[u] = bp[4 * u * HS]; }
+    for (int k0 = 0; k0 < nk; k0 += 4) {
+      float ac[4], bc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { ac[u] = an[u]; bc[u] = bn[u]; }
+      if (k0 + 4 < nk) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { an[u] = ap[4 * (k0 + 4 + u)]; bn[u] = bp[4 * (k0 + 4 + u) * HS]; }
+      }
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[0], bc[0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[1], bc[1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[2], bc[2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[3], bc[3], acc1, 0, 0, 0);
+    }
+    f32x4 acc = acc0 + acc1;
     float bb = b0s[nh * 16 + l15];
 #pragma unroll
     for (int r = 0; r < 4; ++r) H1s[(et * 16 + 4 * g + r) * HS + nh * 16 + l15] = fmaxf(acc[r] + bb, 0.f);
   }
   __syncthreads();
+  if (a.stop == 4) return;
 
   // ---- P4: layers 32->8->1, sigmoid, Keras BCE and their backward.  thread = (example e, unit u)
   {
@@ -238,15 +282,37 @@ __global__ __launch_bounds__(256) void deepfm_fwd_bwd_kernel(Cols cols, FusedArg
     }
   }
 
+  if (a.stop == 5) return;
+
   // ---- P5: dX = dpre1 . K0^T on the matrix cores, fused with the IndexedSlices values.  fields split by nh
   {
     const int f_lo = nh * ((F + 1) / 2), f_hi = nh ? F : (F + 1) / 2;
     const float* ap = DP1 + (et * 16 + l15) * HS + g;
-    for (int f = f_lo; f < f_hi; ++f) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const float* bp = K0s + (f * E16 + l15) * HS + g;
+    float av[U1 / 4];
 #pragma unroll
-      for (int kk = 0; kk < U1 / 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * kk], bp[4 * kk], acc, 0, 0, 0);
+    for (int kk = 0; kk < U1 / 4; ++kk) av[kk] = ap[4 * kk];
+    float bn[U1 / 4];
+    {
+      const float* bp = K0s + (f_lo * E16 + l15) * HS + g;
+#pragma unroll
+      for (int kk = 0; kk < U1 / 4; ++kk) bn[kk] = f_lo < f_hi ? bp[4 * kk] : 0.f;
+    }
+    for (int f = f_lo; f < f_hi; ++f) {
+      float bc[U1 / 4];
+#pragma unroll
+      for (int kk = 0; kk < U1 / 4; ++kk) bc[kk] = bn[kk];
+      if (f + 1 < f_hi) {
+        const float* bp = K0s + ((f + 1) * E16 + l15) * HS + g;
+#pragma unroll
+        for (int kk = 0; kk < U1 / 4; ++kk) bn[kk] = bp[4 * kk];
+      }
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < U1 / 4; kk += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bc[kk], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk + 1], bc[kk + 1], acc1, 0, 0, 0);
+      }
+      f32x4 acc = acc0 + acc1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int e = et * 16 + 4 * g + r;
@@ -257,6 +323,8 @@ __global__ __launch_bounds__(256) void deepfm_fwd_bwd_kernel(Cols cols, FusedArg
       }
     }
   }
+
+  if (a.stop == 6) return;
 
   // ---- P6: per-workgroup dK0 = X^T . dpre1 on the matrix cores.  wave (et, nh) covers all fields for its 16 examples
   {
@@ -355,7 +423,7 @@ __global__ __launch_bounds__(1024) void deepfm_reduce_kernel(const float* __rest
 
 size_t fused_lds_bytes(int F) {
   size_t D = (size_t)F * E16;
-  size_t f = (size_t)EX * (D + 2) + D * HS + 2 * (size_t)EX * HS + (size_t)EX * E16 + 2 * (size_t)EX * F + 2 * (size_t)EX * U2 +
+  size_t f = (size_t)EX * (D + 2) + D * HS + 2 * (size_t)EX * HS + (size_t)EX * E16 + 2 * (size_t)EX * U2 +
              3 * (size_t)EX + U1 * U2 + U1 + 2 * U2;
   return f * sizeof(float);
 }
@@ -454,30 +522,40 @@ __global__ __launch_bounds__(256) void colsort_chunk_kernel(Cols cols, const int
 }
 
 __global__ __launch_bounds__(256) void colsort_rank_kernel(ColSortArgs a) {
-  extern __shared__ uint32_t col[];                    // [nch][CHK]
+  // the other chunks of the column pass through LDS one at a time (two 4-KB buffers, one barrier per chunk): 8 KB
+  // of LDS, so these workgroups fit next to the 122-KB workgroups of the fused kernel on a CU
+  __shared__ uint32_t buf[2][CHK];
   const int tid = threadIdx.x;
   const int ch = blockIdx.x, f = blockIdx.y;
-  const uint32_t* src = a.chunks + (int64_t)f * a.nch * CHK;
-  for (int i = tid; i < a.nch * CHK; i += 256) col[i] = src[i];
-  __syncthreads();
+  const uint32_t* col = a.chunks + (int64_t)f * a.nch * CHK;
+  uint32_t x[4];
+  int pos[4];
+  {
+    uint4 own = reinterpret_cast<const uint4*>(col + (int64_t)ch * CHK)[tid];
+    x[0] = own.x; x[1] = own.y; x[2] = own.z; x[3] = own.w;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    int mine = tid * 4 + r;
-    uint32_t x = col[ch * CHK + mine];
-    if (x == PADW) continue;
-    int pos = mine;                                    // words < x in the own (sorted, unique) chunk
-    for (int c2 = 0; c2 < a.nch; ++c2) {
-      if (c2 == ch) continue;
-      const uint32_t* cc = col + c2 * CHK;
-      int lo = 0;                                      // lower bound: number of words < x
+    for (int r = 0; r < 4; ++r) pos[r] = tid * 4 + r;    // words < x in the own (sorted, unique) chunk
+  }
+  int pp = 0;
+  for (int c2 = 0; c2 < a.nch; ++c2) {
+    if (c2 == ch) continue;
+    reinterpret_cast<uint4*>(buf[pp])[tid] = reinterpret_cast<const uint4*>(col + (int64_t)c2 * CHK)[tid];
+    __syncthreads();
+    const uint32_t* cc = buf[pp];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int lo = 0;                                        // lower bound: number of words < x
 #pragma unroll
       for (int step = CHK / 2; step > 0; step >>= 1)
-        if (cc[lo + step - 1] < x) lo += step;
-      if (cc[lo] < x) ++lo;                            // CHK is a power of two: one last probe
-      pos += lo;
+        if (cc[lo + step - 1] < x[r]) lo += step;
+      if (cc[lo] < x[r]) ++lo;                           // CHK is a power of two: one last probe
+      pos[r] += lo;
     }
-    a.sorted[(int64_t)f * a.B + pos] = x;
+    pp ^= 1;
   }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (x[r] != PADW) a.sorted[(int64_t)f * a.B + pos[r]] = x[r];
 }
 
 template <int NPT>   // sorted positions per thread; 1024 threads cover NPT*1024 >= B
@@ -551,13 +629,16 @@ __global__ __launch_bounds__(256) void colseg_sum_kernel(const float4* __restric
   const int f = (int)(grp / B);
   const int u = (int)(grp - (int64_t)f * B);
   const bool in_range = f < F;
+  __shared__ int nu_s[REC_MAX_COLS];
+  if (tid < F) nu_s[tid] = col_nu[tid];
+  __syncthreads();
   int64_t before = 0, total = 0;               // unique ids in earlier columns / in all columns
   for (int q = 0; q < F; ++q) {
-    int nq = col_nu[q];
+    int nq = nu_s[q];
     if (q < f) before += nq;
     total += nq;
   }
-  const int nu = in_range ? col_nu[f] : 0;
+  const int nu = in_range ? nu_s[f] : 0;
   const bool live = in_range && u < nu;
   int s0 = 0, s1 = 0;
   if (live) {
@@ -653,7 +734,8 @@ extern "C" int rec_deepfm_fused_fwd_bwd_f32(const float* table, int64_t ld, int6
   int nwg = (int)ceil_div64(B, EX);
   float* dK0part = (float*)workspace;
   float* small = dK0part + (size_t)nwg * F * E16 * U1;
-  FusedArgs a{table, V, bias, K0, b0, K1, b1, K2, b2, label, B, F, gz, vals, prob, dK0part, small, oob_flag};
+  static const int stop = getenv("REC_FUSED_STOP") ? atoi(getenv("REC_FUSED_STOP")) : 0;   // diagnostics only
+  FusedArgs a{table, V, bias, K0, b0, K1, b1, K2, b2, label, B, F, gz, vals, prob, dK0part, small, oob_flag, stop};
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(deepfm_fwd_bwd_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
@@ -701,8 +783,7 @@ extern "C" int rec_colsort_plan_i64(const int64_t* const* cols_host, int F, int6
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(colsort_chunk_kernel, dim3(nch, F), dim3(256), 0, st, cp, col_lo, a);
   REC_LAUNCH_CHECK();
-  size_t lds = sizeof(uint32_t) * (size_t)nch * CHK;
-  hipLaunchKernelGGL(colsort_rank_kernel, dim3(nch, F), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(colsort_rank_kernel, dim3(nch, F), dim3(256), 0, st, a);
   REC_LAUNCH_CHECK();
   switch (nch) {
     case 1: hipLaunchKernelGGL(colsort_heads_kernel<1>, dim3(F), dim3(1024), 0, st, col_lo, a); break;

@@ -293,10 +293,13 @@ class DeepFMFusedStep:
             "bias": torch.empty(1, **f32),
         }
         self.ws = torch.empty(lib.rec_deepfm_fused_workspace_bytes(B, F), dtype=torch.uint8, device=dev)
-        self.perm = torch.empty((F, B), dtype=torch.int32, device=dev)
-        self.col_uid = torch.empty((F, B), dtype=torch.int64, device=dev)
-        self.col_seg = torch.empty((F, B + 1), dtype=torch.int32, device=dev)
-        self.col_nu = torch.zeros(F, dtype=torch.int32, device=dev)
+        # two plan buffers: the de-duplication plan depends on the ids only, so the plan of batch k+1 can be built
+        # (second stream) while batch k is being differentiated
+        self.plans = [dict(perm=torch.empty((F, B), dtype=torch.int32, device=dev),
+                           col_uid=torch.empty((F, B), dtype=torch.int64, device=dev),
+                           col_seg=torch.empty((F, B + 1), dtype=torch.int32, device=dev),
+                           col_nu=torch.zeros(F, dtype=torch.int32, device=dev)) for _ in range(2)]
+        self._plan_key, self._plan_buf = None, 0
         self.uniq_ids = torch.empty(n, dtype=torch.int64, device=dev)
         self.g_embed_rows = torch.empty((n, 16), **f32)
         self.g_w_rows = torch.empty((n, 1), **f32)
@@ -310,17 +313,30 @@ class DeepFMFusedStep:
             self.side_w = torch.empty((n, 3, 1), **f32)
         self._graphs = {}
 
-    def _enqueue(self, cols, label, t):
+    def _sort(self, cols, buf, stream):
+        F = self.F
+        arr = (C.c_void_p * F)(*[c.data_ptr() for c in cols])
+        pl = self.plans[buf]
+        check(lib.rec_colsort_plan_i64(arr, F, self.B, self.V, _p(self.col_lo), self.max_key, _p(pl["perm"]),
+                                       _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.bad_ids),
+                                       _p(self.sort_ws), C.c_void_p(stream.cuda_stream)), "rec_colsort_plan_i64")
+
+    def _enqueue(self, cols, label, t, cur, have_plan, next_cols):
+        """cur: plan buffer of this batch; have_plan: it was filled by the previous step; next_cols: columns of
+        the next batch, whose plan is built into the other buffer concurrently (second stream)."""
         L = self.layer
         F, B, V = self.F, self.B, self.V
         arr = (C.c_void_p * F)(*[c.data_ptr() for c in cols])
         main = torch.cuda.current_stream()
         side = self.side_stream
-        side.wait_stream(main)                                   # fork: the sort only needs the ids
-        with torch.cuda.stream(side):
-            check(lib.rec_colsort_plan_i64(arr, F, B, V, _p(self.col_lo), self.max_key, _p(self.perm),
-                                           _p(self.col_uid), _p(self.col_seg), _p(self.col_nu), _p(self.bad_ids),
-                                           _p(self.sort_ws), C.c_void_p(side.cuda_stream)), "rec_colsort_plan_i64")
+        forked = (not have_plan) or (next_cols is not None)
+        if forked:
+            side.wait_stream(main)                               # fork: a sort only needs ids
+            with torch.cuda.stream(side):
+                if not have_plan:
+                    self._sort(cols, cur, side)                  # this batch's own plan (non-pipelined call)
+                if next_cols is not None:
+                    self._sort(next_cols, 1 - cur, side)         # the next batch's plan
         st = C.c_void_p(main.cuda_stream)
         g = self.g
         emb = L.embed.embeddings
@@ -331,12 +347,16 @@ class DeepFMFusedStep:
             _p(g["MLP_layer1.kernel_1"]), _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]),
             _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(self.loss), _p(self.oob), _p(self.ws), st),
             "rec_deepfm_fused_fwd_bwd_f32")
-        main.wait_stream(side)                                   # join
-        check(lib.rec_colseg_sum_f32(_p(self.vals), _p(self.gz), _p(self.perm), _p(self.col_uid), _p(self.col_seg),
-                                     _p(self.col_nu), B, F, _p(self.uniq_ids), _p(self.g_embed_rows),
+        if forked and not have_plan:
+            main.wait_stream(side)                               # this batch's plan is needed now
+        pl = self.plans[cur]
+        check(lib.rec_colseg_sum_f32(_p(self.vals), _p(self.gz), _p(pl["perm"]), _p(pl["col_uid"]), _p(pl["col_seg"]),
+                                     _p(pl["col_nu"]), B, F, _p(self.uniq_ids), _p(self.g_embed_rows),
                                      _p(self.g_w_rows), _p(self.n_uniq), st), "rec_colseg_sum_f32")
         if self.optimizer is not None:
             self._optimizer(t, st)
+        if forked and have_plan:
+            main.wait_stream(side)                               # join: the next step may rely on the other buffer
 
     def _optimizer(self, t, st):
         lr, b1, b2, eps = self.lr, 0.9, 0.999, 1e-7
@@ -358,31 +378,48 @@ class DeepFMFusedStep:
                 check(lib.rec_adam_rows_f32(_p(p), p.stride(0), _p(m), _p(v), self.V, E, _p(self.uniq_ids), _p(rows),
                                             _p(self.n_uniq), n, t, lr, b1, b2, eps, st), "rec_adam_rows_f32")
 
-    def __call__(self, inputs, label_name="label"):
+    def _cols(self, inputs):
         cols = []
         for name in self.layer.feature_names:
             c = inputs[name]
             if c.dtype != torch.int64 or not c.is_cuda or c.numel() != self.B or not c.is_contiguous():
                 raise ValueError("feature %r must be a contiguous int64 CUDA tensor with %d ids" % (name, self.B))
             cols.append(c)
+        return cols
+
+    def __call__(self, inputs, label_name="label", next_inputs=None):
+        """One train_loop iteration on `inputs`.  ``next_inputs`` (optional) = the batch of the NEXT call: its
+        de-duplication plan is built on the second stream while this batch is differentiated (input-pipeline style
+        prefetch: the plan depends on ids only).  Without it, or when the previous call did not announce this batch,
+        the plan is built inside this call."""
+        cols = self._cols(inputs)
         y = inputs[label_name]
         if y.dtype != torch.float32 or not y.is_cuda or y.numel() != self.B or not y.is_contiguous():
             raise ValueError("label must be a contiguous float32 CUDA tensor with %d entries" % self.B)
+        next_cols = self._cols(next_inputs) if next_inputs is not None else None
+        key = tuple(c.data_ptr() for c in cols)
+        next_key = tuple(c.data_ptr() for c in next_cols) if next_cols is not None else None
+        have_plan = self._plan_key is not None and self._plan_key == key
+        cur = self._plan_buf if have_plan else 0
         self.t += 1
         if not self.use_graph or self.optimizer is not None:
-            self._enqueue(cols, y, self.t)
-            return self.loss
-        key = tuple(c.data_ptr() for c in cols) + (y.data_ptr(),)
-        ent = self._graphs.get(key)
-        if ent is None:
-            self._enqueue(cols, y, self.t)                       # warm-up (also sets the kernel attributes)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._enqueue(cols, y, self.t)
-            ent = (g, cols, y)
-            self._graphs[key] = ent
-        ent[0].replay()
+            self._enqueue(cols, y, self.t, cur, have_plan, next_cols)
+        else:
+            gkey = (key, y.data_ptr(), next_key, cur, have_plan)
+            ent = self._graphs.get(gkey)
+            if ent is None:
+                self._enqueue(cols, y, self.t, cur, have_plan, next_cols)   # warm-up (sets the kernel attributes)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._enqueue(cols, y, self.t, cur, have_plan, next_cols)
+                ent = (g, cols, y, next_cols)                    # keep the inputs alive: the graph holds addresses
+                self._graphs[gkey] = ent
+            ent[0].replay()
+        if next_cols is not None:
+            self._plan_key, self._plan_buf = next_key, 1 - cur
+        else:
+            self._plan_key = None
         return self.loss
 
     def check_flags(self):

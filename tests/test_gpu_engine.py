@@ -186,6 +186,33 @@ def test_fused_step_matches_oracle(use_graph, B, F, V, dist):
             assert np.all(rows.cpu().numpy()[nu:] == 0) and np.all(ids.cpu().numpy()[nu:] == touched[0])
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_fused_step_pipelined_plan(use_graph):
+    """``next_inputs``: the plan of batch k+1 is built (second stream) while batch k is differentiated; every step
+    must still deliver batch k's own gradients -- also when an announced batch is NOT the one that follows."""
+    from explicit_tf2_recommendation_amd import engine, data
+    B, F, V = 2048, 26, 300000
+    layer, names, gen = make16(B, F, V, 23, "zipf")
+    step = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, use_graph=use_graph)
+    host = [gen.batch(B) for _ in range(3)]
+    devb = [data.to_device(b) for b in host]
+    refs = [oracle_grads(layer, names, b) for b in host]
+    order = [(0, 1), (1, 2), (2, 0), (0, 1), (1, 2), (0, 2), (2, None), (1, 0)]   # (batch, announced next batch)
+    for cur, nxt in order:
+        loss = step(devb[cur], next_inputs=devb[nxt] if nxt is not None else None)
+        step.check_flags()
+        ref_loss, ref = refs[cur]
+        assert abs(loss.item() - ref_loss) <= 1e-5 * max(1, abs(ref_loss)), (cur, nxt)
+        g = step.gradients()
+        touched = np.unique(L.index_assemble(host[cur], names))
+        ids, rows, nu = g["embed.embeddings"]
+        nu = int(nu.item())
+        assert np.array_equal(ids.cpu().numpy()[:nu], touched), (cur, nxt)
+        assert close(rows.cpu().numpy()[:nu], ref["embed.embeddings"][touched]), (cur, nxt)
+        assert close(g["w.embeddings"][1].cpu().numpy()[:nu], ref["w.embeddings"][touched]), (cur, nxt)
+        assert close(g["MLP_layer1.kernel_0"].cpu().numpy(), ref["MLP_layer1.kernel_0"]), (cur, nxt)
+
+
 def test_fused_step_equals_generic_step_and_is_deterministic():
     from explicit_tf2_recommendation_amd import engine, data
     B, F, V = 4096, 26, 500000
