@@ -23,7 +23,7 @@ SIGNATURES = {
     "rec_dedup_plan_i64": (i32, [p, i64, i64, p, p, p, p, p, sz, p]),
     "rec_segment_sum_workspace_bytes": (sz, [i64, i32]),
     "rec_segment_sum_f32": (i32, [p, i32, p, p, i64, i32, p, p, p]),
-    "rec_gemm_f32": (i32, [i32, i32, i64, i64, i64, p, i64, p, i64, p, i64, i32, p, p, i64, p, i64, i32, p, p]),
+    "rec_gemm_f32": (i32, [i32, i32, i64, i64, i64, p, i64, p, i64, p, i64, i32, p, p, i64, p, i64, i32, p, p, p]),
     "rec_act_fwd_f32": (i32, [i32, p, p, p, i64, p]),
     "rec_crossnet_mat_bwd_elem_f32": (i32, [p, p, p, p, p, i32, i64, p]),
     "rec_act_bwd_f32": (i32, [i32, p, p, p, i64, p]),

@@ -16,13 +16,18 @@ constexpr int BM = 64, BN = 64, BK = 16, PAD = 1;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float epilogue(int epi, float acc, int64_t gm, int64_t gn, const float* bias,
-                                          const float* e0, int64_t lde0, const float* e1, int64_t lde1) {
+                                          const float* e0, int64_t lde0, const float* e1, int64_t lde1,
+                                          float* aux = nullptr, int64_t ldaux = 0) {
   switch (epi) {
     case REC_EPI_BIAS: return acc + bias[gn];
     case REC_EPI_BIAS_RELU: return fmaxf(acc + bias[gn], 0.f);
     case REC_EPI_BIAS_SIGMOID: return sigmoid_acc(acc + bias[gn]);
     case REC_EPI_BIAS_TANH: return tanhf(acc + bias[gn]);
-    case REC_EPI_CROSS: return e0[gm * lde0 + gn] * (acc + bias[gn]) + e1[gm * lde1 + gn];
+    case REC_EPI_CROSS: {
+      float u = acc + bias[gn];
+      if (aux) aux[gm * ldaux + gn] = u;      // U_l = x_l W_l^T + b_l, kept for the backward pass
+      return e0[gm * lde0 + gn] * u + e1[gm * lde1 + gn];
+    }
     case REC_EPI_ADD: return acc + e1[gm * lde1 + gn];
     default: return acc;
   }
@@ -34,7 +39,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int64_t M, int64_t N, int
                                                        float* __restrict__ C, int64_t ldc, int epi,
                                                        const float* __restrict__ bias, const float* __restrict__ e0,
                                                        int64_t lde0, const float* __restrict__ e1, int64_t lde1,
-                                                       int64_t kchunk, float* __restrict__ ws) {
+                                                       int64_t kchunk, float* __restrict__ ws, float* __restrict__ aux) {
   __shared__ float As[BK][BM + PAD];
   __shared__ float Bs[BK][BN + PAD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -87,22 +92,113 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int64_t M, int64_t N, int
       if (ws) {
         ws[((int64_t)blockIdx.z * M + gm) * N + gn] = acc[r];
       } else {
-        C[gm * ldc + gn] = epilogue(epi, acc[r], gm, gn, bias, e0, lde0, e1, lde1);
+        C[gm * ldc + gn] = epilogue(epi, acc[r], gm, gn, bias, e0, lde0, e1, lde1, aux, ldc);
       }
     }
   }
 }
 
+// ---- large-tile variant: 128x128x16 block tile, 4 waves as 2x2, each wave a 64x64 patch = 2x2 MFMA 32x32 tiles
+// (64 accumulator registers), the next K-tile prefetched into registers while the current one is multiplied (one
+// barrier pair per K-tile, global latency hidden behind 32 MFMAs per wave).  Used when both M and N are large
+// (CrossNet matrix mode, DIN q.Wcat); same guarded scalar loads, so any shape / leading dimension works.
+constexpr int LM = 128, LN = 128, LK = 16, LPAD = 4;
+
+template <int TA, int TB>
+__global__ __launch_bounds__(256) void gemm_f32_big_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A,
+                                                           int64_t lda, const float* __restrict__ B, int64_t ldb,
+                                                           float* __restrict__ C, int64_t ldc, int epi,
+                                                           const float* __restrict__ bias, const float* __restrict__ e0,
+                                                           int64_t lde0, const float* __restrict__ e1, int64_t lde1,
+                                                           int64_t kchunk, float* __restrict__ ws, float* __restrict__ aux) {
+  __shared__ float As[LK][LM + LPAD];
+  __shared__ float Bs[LK][LN + LPAD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.x * LM, n0 = (int64_t)blockIdx.y * LN;
+  const int64_t k_begin = (int64_t)blockIdx.z * kchunk;
+  const int64_t k_end = (k_begin + kchunk < K) ? k_begin + kchunk : K;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  constexpr int PER = (LM * LK) / 256;   // 8 elements of each operand per thread and K-tile
+  float ra[PER], rb[PER];
+  auto fetch = [&](int64_t k0) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int e = tid + i * 256;
+      int m, k;
+      if (TA == 0) { m = e / LK; k = e % LK; } else { k = e / LM; m = e % LM; }
+      int64_t gm = m0 + m, gk = k0 + k;
+      ra[i] = (gm < M && gk < k_end) ? ((TA == 0) ? A[gm * lda + gk] : A[gk * lda + gm]) : 0.f;
+      int n, k2;
+      if (TB == 0) { k2 = e / LN; n = e % LN; } else { n = e / LK; k2 = e % LK; }
+      int64_t gn = n0 + n, gk2 = k0 + k2;
+      rb[i] = (gn < N && gk2 < k_end) ? ((TB == 0) ? B[gk2 * ldb + gn] : B[gn * ldb + gk2]) : 0.f;
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int e = tid + i * 256;
+      if (TA == 0) As[e % LK][e / LK] = ra[i]; else As[e / LM][e % LM] = ra[i];
+      if (TB == 0) Bs[e / LN][e % LN] = rb[i]; else Bs[e % LK][e / LK] = rb[i];
+    }
+  };
+
+  if (k_begin < k_end) fetch(k_begin);
+  for (int64_t k0 = k_begin; k0 < k_end; k0 += LK) {
+    stage();
+    __syncthreads();
+    if (k0 + LK < k_end) fetch(k0 + LK);               // in flight while this tile is multiplied
+#pragma unroll
+    for (int kk = 0; kk < LK; kk += 2) {
+      float a0 = As[kk + (lane >> 5)][wm * 64 + (lane & 31)];
+      float a1 = As[kk + (lane >> 5)][wm * 64 + 32 + (lane & 31)];
+      float b0 = Bs[kk + (lane >> 5)][wn * 64 + (lane & 31)];
+      float b1 = Bs[kk + (lane >> 5)][wn * 64 + 32 + (lane & 31)];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  const int col = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t gn = n0 + wn * 64 + j * 32 + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int64_t gm = m0 + wm * 64 + i * 32 + row;
+        if (gm < M && gn < N) {
+          if (ws) ws[((int64_t)blockIdx.z * M + gm) * N + gn] = acc[i][j][r];
+          else C[gm * ldc + gn] = epilogue(epi, acc[i][j][r], gm, gn, bias, e0, lde0, e1, lde1, aux, ldc);
+        }
+      }
+    }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int split, int64_t M,
                                                             int64_t N, float* __restrict__ C, int64_t ldc, int epi,
                                                             const float* __restrict__ bias, const float* __restrict__ e0,
-                                                            int64_t lde0, const float* __restrict__ e1, int64_t lde1) {
+                                                            int64_t lde0, const float* __restrict__ e1, int64_t lde1,
+                                                            float* __restrict__ aux) {
   int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= M * N) return;
   int64_t gm = t / N, gn = t - gm * N;
   float acc = 0.f;
   for (int z = 0; z < split; ++z) acc += ws[(int64_t)z * M * N + t];  // fixed order
-  C[gm * ldc + gn] = epilogue(epi, acc, gm, gn, bias, e0, lde0, e1, lde1);
+  C[gm * ldc + gn] = epilogue(epi, acc, gm, gn, bias, e0, lde0, e1, lde1, aux, ldc);
 }
 
 }  // namespace
@@ -110,7 +206,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 extern "C" int rec_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                             const float* B, int64_t ldb, float* C, int64_t ldc, int epilogue_kind,
                             const float* bias, const float* e0, int64_t lde0, const float* e1, int64_t lde1,
-                            int split_k, float* workspace, void* stream) {
+                            int split_k, float* workspace, float* aux, void* stream) {
   if (!A || !B || !C || M < 0 || N < 0 || K < 0) return REC_E_ARG;
   if (epilogue_kind < REC_EPI_NONE || epilogue_kind > REC_EPI_ADD) return REC_E_ARG;
   if (epilogue_kind >= REC_EPI_BIAS && epilogue_kind <= REC_EPI_CROSS && !bias) return REC_E_ARG;
@@ -128,21 +224,35 @@ extern "C" int rec_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
     if (split_k < 1) split_k = 1;
   }
   float* ws = split_k > 1 ? workspace : nullptr;
-  dim3 grid((unsigned)ceil_div64(M, BM), (unsigned)ceil_div64(N, BN), (unsigned)split_k);
-  if (grid.y > 65535u) return REC_E_UNSUPPORTED;
   hipStream_t st = as_stream(stream);
+  const bool big = M > 64 && N > 64;
+  if (big) {
+    dim3 grid((unsigned)ceil_div64(M, LM), (unsigned)ceil_div64(N, LN), (unsigned)split_k);
+    if (grid.y > 65535u) return REC_E_UNSUPPORTED;
+#define LAUNCHB(TA, TB)                                                                                       \
+  hipLaunchKernelGGL((gemm_f32_big_kernel<TA, TB>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc,  \
+                     epilogue_kind, bias, e0, lde0, e1, lde1, kchunk, ws, aux)
+    if (!transA && !transB) LAUNCHB(0, 0);
+    else if (!transA && transB) LAUNCHB(0, 1);
+    else if (transA && !transB) LAUNCHB(1, 0);
+    else LAUNCHB(1, 1);
+#undef LAUNCHB
+  } else {
+    dim3 grid((unsigned)ceil_div64(M, BM), (unsigned)ceil_div64(N, BN), (unsigned)split_k);
+    if (grid.y > 65535u) return REC_E_UNSUPPORTED;
 #define LAUNCH(TA, TB)                                                                                        \
   hipLaunchKernelGGL((gemm_f32_kernel<TA, TB>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc,      \
-                     epilogue_kind, bias, e0, lde0, e1, lde1, kchunk, ws)
-  if (!transA && !transB) LAUNCH(0, 0);
-  else if (!transA && transB) LAUNCH(0, 1);
-  else if (transA && !transB) LAUNCH(1, 0);
-  else LAUNCH(1, 1);
+                     epilogue_kind, bias, e0, lde0, e1, lde1, kchunk, ws, aux)
+    if (!transA && !transB) LAUNCH(0, 0);
+    else if (!transA && transB) LAUNCH(0, 1);
+    else if (transA && !transB) LAUNCH(1, 0);
+    else LAUNCH(1, 1);
 #undef LAUNCH
+  }
   REC_LAUNCH_CHECK();
   if (ws) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div64(M * N, 256)), dim3(256), 0, st, ws, split_k,
-                       M, N, C, ldc, epilogue_kind, bias, e0, lde0, e1, lde1);
+                       M, N, C, ldc, epilogue_kind, bias, e0, lde0, e1, lde1, aux);
     REC_LAUNCH_CHECK();
   }
   return REC_OK;

@@ -123,35 +123,35 @@ class DeepFMTrainStep:
         P.add("rec_emb_fm_fwd_f32", _p(emb), emb.stride(0), _p(w), w.stride(0), _p(bias), V, E, _p(self.X), B, F,
               _p(self.z_fm), None, _p(self.rows), _p(self.S), _p(self.oob))
         P.add("rec_gemm_f32", 0, 0, B, u1, D, _p(self.rows), D, _p(K0), u1, _p(self.h1), u1, ops.EPI_BIAS_RELU, _p(b0),
-              None, 0, None, 0, 1, None)
+              None, 0, None, 0, 1, None, None)
         P.add("rec_gemm_f32", 0, 0, B, u2, u1, _p(self.h1), u1, _p(K1), u2, _p(self.h2), u2, ops.EPI_BIAS_RELU, _p(b1),
-              None, 0, None, 0, 1, None)
+              None, 0, None, 0, 1, None, None)
         P.add("rec_gemm_f32", 0, 0, B, 1, u2, _p(self.h2), u2, _p(K2), 1, _p(self.dnn), 1, ops.EPI_BIAS, _p(b2),
-              None, 0, None, 0, 1, None)
+              None, 0, None, 0, 1, None, None)
         P.add("rec_act_fwd_f32", ops.ACT_SIGMOID, _p(self.dnn), _p(self.z_fm), _p(self.prob), B)
         self._loss_call_index = len(P.calls)
         P.add("rec_bce_fwd_bwd_f32", None, _p(self.prob), B, _p(self.loss), None, _p(self.dz))   # y bound per batch
         # ---- backward: MLP_layer2 (linear)
         g = self.g
         P.add("rec_gemm_f32", 1, 0, u2, 1, B, _p(self.h2), u2, _p(self.dz), 1, _p(g["MLP_layer2.kernel_0"]), 1,
-              ops.EPI_NONE, None, None, 0, None, 0, self.sk2, _p(self.ws2))
+              ops.EPI_NONE, None, None, 0, None, 0, self.sk2, _p(self.ws2), None)
         P.add("rec_colsum_f32", _p(self.dz), B, 1, 1, _p(g["MLP_layer2.bias_0"]), _p(self.colsum_ws))
         P.add("rec_gemm_f32", 0, 1, B, u2, 1, _p(self.dz), 1, _p(K2), 1, _p(self.dh2), u2, ops.EPI_NONE, None, None, 0,
-              None, 0, 1, None)
+              None, 0, 1, None, None)
         # ---- MLP_layer1 layer 1 (relu)
         P.add("rec_act_bwd_f32", ops.ACT_RELU, _p(self.h2), _p(self.dh2), _p(self.dh2), B * u2)
         P.add("rec_gemm_f32", 1, 0, u1, u2, B, _p(self.h1), u1, _p(self.dh2), u2, _p(g["MLP_layer1.kernel_1"]), u2,
-              ops.EPI_NONE, None, None, 0, None, 0, self.sk1, _p(self.ws1))
+              ops.EPI_NONE, None, None, 0, None, 0, self.sk1, _p(self.ws1), None)
         P.add("rec_colsum_f32", _p(self.dh2), B, u2, u2, _p(g["MLP_layer1.bias_1"]), _p(self.colsum_ws))
         P.add("rec_gemm_f32", 0, 1, B, u1, u2, _p(self.dh2), u2, _p(K1), u2, _p(self.dh1), u1, ops.EPI_NONE, None, None,
-              0, None, 0, 1, None)
+              0, None, 0, 1, None, None)
         # ---- MLP_layer1 layer 0 (relu)
         P.add("rec_act_bwd_f32", ops.ACT_RELU, _p(self.h1), _p(self.dh1), _p(self.dh1), B * u1)
         P.add("rec_gemm_f32", 1, 0, D, u1, B, _p(self.rows), D, _p(self.dh1), u1, _p(g["MLP_layer1.kernel_0"]), u1,
-              ops.EPI_NONE, None, None, 0, None, 0, self.sk0, _p(self.ws0))
+              ops.EPI_NONE, None, None, 0, None, 0, self.sk0, _p(self.ws0), None)
         P.add("rec_colsum_f32", _p(self.dh1), B, u1, u1, _p(g["MLP_layer1.bias_0"]), _p(self.colsum_ws))
         P.add("rec_gemm_f32", 0, 1, B, D, u1, _p(self.dh1), u1, _p(K0), u1, _p(self.drows), D, ops.EPI_NONE, None, None,
-              0, None, 0, 1, None)
+              0, None, 0, 1, None, None)
         # ---- tables: IndexedSlices values, de-duplication, segment sums
         P.add("rec_emb_fm_bwd_vals_f32", _p(emb), emb.stride(0), V, E, _p(self.X), B, F, _p(self.dz), _p(self.S),
               _p(self.rows), _p(self.drows), _p(self.vals))

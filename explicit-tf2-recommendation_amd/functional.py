@@ -128,17 +128,21 @@ class CrossMat(torch.autograd.Function):
     def forward(ctx, x0, W, b):
         x0 = x0.contiguous()
         L = W.shape[0]
-        xs = [x0]
+        xs, us = [x0], []
         for l in range(L):
-            xs.append(ops.gemm(xs[-1], W[l], transB=True, epi=ops.EPI_CROSS, bias=b[l], e0=x0, e1=xs[-1]))
-        ctx.save_for_backward(x0, W, b, *xs[:-1])
+            u = torch.empty_like(x0)                     # U_l = x_l W_l^T + b_l, written by the GEMM epilogue
+            xs.append(ops.gemm(xs[-1], W[l], transB=True, epi=ops.EPI_CROSS, bias=b[l], e0=x0, e1=xs[-1], aux=u))
+            us.append(u)
+        ctx.L = L
+        ctx.save_for_backward(x0, W, b, *xs[:-1], *us)
         return xs[-1]
 
     @staticmethod
     def backward(ctx, gy):
         x0, W, b = ctx.saved_tensors[:3]
-        xs = ctx.saved_tensors[3:]
-        L = W.shape[0]
+        L = ctx.L
+        xs = ctx.saved_tensors[3:3 + L]
+        us = ctx.saved_tensors[3 + L:]
         B, D = x0.shape
         g = gy.contiguous()
         gx0 = torch.empty_like(x0)
@@ -146,8 +150,7 @@ class CrossMat(torch.autograd.Function):
         db = torch.empty_like(b)
         for l in range(L - 1, -1, -1):
             xl = xs[l]
-            # U_l = x_l W_l^T + b_l is recomputed (one GEMM) instead of being kept from the forward
-            u = ops.gemm(xl, W[l], transB=True, epi=ops.EPI_BIAS, bias=b[l])
+            u = us[l]
             h = ops.crossnet_mat_bwd_elem(g, x0, u, gx0, accumulate=(l != L - 1))   # H = G(.)X0 ; dX0 += G(.)U
             ops.gemm(h, xl, transA=True, split_k=ops.split_k_for(B, D, D), out=dW[l])
             ops.colsum(h, out=db[l])

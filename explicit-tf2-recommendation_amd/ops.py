@@ -155,7 +155,7 @@ class DedupPlan:
 # dense
 # ---------------------------------------------------------------------------------------------------
 
-def gemm(A, B, transA=False, transB=False, epi=EPI_NONE, bias=None, e0=None, e1=None, split_k=1, out=None):
+def gemm(A, B, transA=False, transB=False, epi=EPI_NONE, bias=None, e0=None, e1=None, split_k=1, out=None, aux=None):
     """C = epi(op(A) @ op(B)) on the fp32 matrix cores.  A, B are 2-D row-major (leading dim = stride(0))."""
     for t, nm in ((A, "A"), (B, "B")):
         if t.dtype != torch.float32 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
@@ -171,7 +171,7 @@ def gemm(A, B, transA=False, transB=False, epi=EPI_NONE, bias=None, e0=None, e1=
         ws = torch.empty((split_k, M, N), dtype=torch.float32, device=A.device)
     check(lib.rec_gemm_f32(int(transA), int(transB), M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out),
                            out.stride(0), epi, _ptr(bias), _ptr(e0), e0.stride(0) if e0 is not None else 0,
-                           _ptr(e1), e1.stride(0) if e1 is not None else 0, split_k, _ptr(ws), _stream()),
+                           _ptr(e1), e1.stride(0) if e1 is not None else 0, split_k, _ptr(ws), _ptr(aux), _stream()),
           "rec_gemm_f32")
     return out
 
@@ -222,10 +222,11 @@ def copy_cols(src, dst_view):
 
 def split_k_for(K, M, N):
     """Heuristic split of a reduction over the batch so that ~>=256 workgroups run."""
-    tiles = ((M + 63) // 64) * ((N + 63) // 64)
-    if tiles >= 256 or K < 1024:
+    t = 128 if (M > 64 and N > 64) else 64          # tile edge the kernel will use
+    tiles = ((M + t - 1) // t) * ((N + t - 1) // t)
+    if tiles >= 512 or K < 1024:
         return 1
-    return int(max(1, min(64, 512 // max(tiles, 1), K // 256)))
+    return int(max(1, min(64, -(-768 // max(tiles, 1)), K // 256)))
 
 
 # ---------------------------------------------------------------------------------------------------

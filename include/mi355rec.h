@@ -104,11 +104,12 @@ int rec_segment_sum_f32(const float* vals, int E, const int32_t* perm, const int
  * transB=0 -> B stored [K,N], transB=1 -> B stored [N,K].  MatMul+BiasAdd+activation of MLPLayer
  * (2.FM/CustomLayers.py:74-81), Keras Dense (3.DCN/CustomLayers.py:158-167), MatrixCrossLayer
  * (3.DCN/CustomLayers.py:301-303, REC_EPI_CROSS with e0=x0, e1=x_l) and their backward GEMMs.
- * split_k > 1 needs workspace of split_k*M*N floats (partials are summed in a fixed order). */
+ * split_k > 1 needs workspace of split_k*M*N floats (partials are summed in a fixed order).
+ * aux (optional, REC_EPI_CROSS only, leading dimension ldc): receives U = A.B + bias, kept for the backward pass. */
 int rec_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                  const float* B, int64_t ldb, float* C, int64_t ldc, int epilogue, const float* bias,
                  const float* e0, int64_t lde0, const float* e1, int64_t lde1, int split_k,
-                 float* workspace, void* stream);
+                 float* workspace, float* aux, void* stream);
 
 /* ---- K6 backward, elementwise part of one MatrixCrossLayer layer: h = g*x0 ; gx0 = (accumulate ? gx0 : 0) + g*u
  * (H = G (.) X0 feeds the dW and dX GEMMs; dX0 += G (.) U_l).  n = B*D. */

@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the other BASELINE.json configs (parity-test cases, NOT the bench.py headline):
+forward + backward through the Layer mirror (autograd over the HIP kernels) on synthetic DataGenerator-contract
+batches, one MI355X.  Prints one JSON line per config.  Usage:  python scripts/bench_configs.py [A B C C26 D E]
+
+  A   FM, 5 fields, V=5547, E=16, B=256                       (BASELINE configs[0], via ModelManager)
+  B   DeepFM, 26 fields, V=1M, E=16, B=8192                   (configs[1]; the 10M variant is bench.py)
+  C   DCN matrix CrossNet, 10 cat + 3 cont, V=10M, E=32, L=3, B=16384 (D=323); C26 = 26 cat fields (D=835)
+  D   DSSM two-tower, item V=100M x 64d on ONE GPU (25.6 GB table; the 8-way sharded form is sharded.py), B=8192
+  E   DIN, T=100, V=50M, E=32, B=4096
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from explicit_tf2_recommendation_amd import layers, data, functional as Fn  # noqa: E402
+from explicit_tf2_recommendation_amd.model_manager import ModelManager  # noqa: E402
+
+
+def timed(fn, warmup, iters):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def fwd_bwd(layer, batch, names_all):
+    ins = {k: batch[k] for k in names_all}
+
+    def step():
+        for p in layer.parameters():
+            p.grad = None
+        out = layer(ins)["output"]
+        y = batch["label"]
+        if out.dim() == 2 and out.shape[1] > 1:
+            y = y.expand(-1, out.shape[1]).contiguous()
+        Fn.KerasBCE.apply(out, y).backward()
+    return step
+
+
+def big_table_(emb):
+    """Fill a very large table on the device (a host-side torch.rand of 25.6 GB would take minutes)."""
+    with torch.no_grad():
+        emb.uniform_(-0.05, 0.05)
+
+
+def run(name):
+    torch.cuda.empty_cache()
+    layers.Layer.check_ids = False          # no per-call device->host read of the bounds flag while timing
+    if name == "A":
+        names = ["user_tag1", "user_tag2", "item_tag1", "item_tag2", "item_tag3"]
+        V, B = 5547, 256
+        mm = ModelManager(feature_names=names, data_info=data.data_info(V, 5), embedding_dims=16, lr=1e-3, batch=B,
+                          layer="fm_ranking")
+        gen = data.SyntheticGenerator(names, V, dist="zipf", seed=0)
+        batches = [gen.batch(B) for _ in range(8)]
+        dt = timed(lambda: mm.train_loop(dict(batches[0])), 5, 50)
+        return {"config": "A FM via ModelManager (train_loop incl. Keras-Adam dense sweep)", "B": B, "V": V,
+                "ms_per_step": dt * 1e3, "examples_per_s": B / dt}
+    if name == "B":
+        names = ["C%d" % i for i in range(26)]
+        V, B = 1_000_000, 8192
+        layer = layers.DeepFMRankingLayer(feature_names=names, feature_dims=V, embedding_dims=16).cuda()
+        batch = data.to_device(data.SyntheticGenerator(names, V, seed=0).batch(B))
+        dt = timed(fwd_bwd(layer, batch, names), 5, 50)
+        return {"config": "B DeepFM 1M x 16d (autograd path; the fused engine is bench.py)", "B": B, "V": V,
+                "ms_per_step": dt * 1e3, "examples_per_s": B / dt}
+    if name in ("C", "C26"):
+        ncat = 10 if name == "C" else 26
+        cat = ["c%d" % i for i in range(ncat)]
+        cont = ["x0", "x1", "x2"]
+        V, B, E, Lyr = 10_000_000, 16384, 32, 3
+        layer = layers.DeepCrossNetworkLayer(categorical_features=cat, continuous_features=cont, feature_dims=V,
+                                             embedding_dims=E, layer_num=Lyr, type="matrix")
+        layer = layer.cuda()
+        batch = data.to_device(data.SyntheticGenerator(cat, V, continuous=cont, seed=0).batch(B))
+        D = 3 + ncat * E
+        dt = timed(fwd_bwd(layer, batch, cat + cont), 3, 20)
+        flops = 2.0 * B * D * D * Lyr * (1 + 3)          # fwd + (recompute U, dW, dX) in bwd
+        return {"config": "%s DCN matrix CrossNet D=%d L=3" % (name, D), "B": B, "V": V, "ms_per_step": dt * 1e3,
+                "examples_per_s": B / dt, "crossnet_gemm_flops_per_step": flops,
+                "crossnet_tflops_if_all_time_were_gemm": flops / dt / 1e12}
+    if name == "D":
+        un, inn = ["user_tag1", "user_tag2"], ["item_tag1", "item_tag2", "item_tag3"]
+        V, B, E = 100_000_000, 8192, 64
+        layer = layers.DSSMTwoTowerRetrievalLayer(u_feature_names=un, i_feature_names=inn, u_feature_dims=1000,
+                                                  i_feature_dims=1000, u_embedding_dims=E, i_embedding_dims=E)
+        layer = layer.cuda()
+        # swap in the big item table directly on the device
+        layer.i_tower.embed.embeddings = torch.nn.Parameter(torch.empty((V, E), device="cuda"))
+        layer.u_tower.embed.embeddings = torch.nn.Parameter(torch.empty((V // 10, E), device="cuda"))
+        big_table_(layer.i_tower.embed.embeddings)
+        big_table_(layer.u_tower.embed.embeddings)
+        gi = data.SyntheticGenerator(inn, V, seed=0).batch(B)
+        gu = data.SyntheticGenerator(un, V // 10, seed=1).batch(B)
+        batch = data.to_device({**{k: gu[k] for k in un}, **{k: gi[k] for k in inn}, "label": gi["label"]})
+        dt = timed(fwd_bwd(layer, batch, un + inn), 3, 20)
+        return {"config": "D DSSM two-tower, item table 100M x 64d (25.6 GB) on one GPU", "B": B, "V": V,
+                "ms_per_step": dt * 1e3, "examples_per_s": B / dt}
+    if name == "E":
+        user = ["uid", "utag1", "utag2", "utag3", "utag4"]
+        item = ["i_goods_id", "i_shop_id", "i_cate_id"]
+        ser = ["visited_goods_ids", "visited_shop_ids", "visited_cate_ids"]
+        V, B, E, T = 50_000_000, 4096, 32, 100
+        layer = layers.DINLayer(user_and_context_categorical_features=user, item_categorical_features=item,
+                                behavior_series_features=ser, feature_dims=1000, embedding_dims=E)
+        layer = layer.cuda()
+        layer.embed.embeddings = torch.nn.Parameter(torch.empty((V, E), device="cuda"))
+        big_table_(layer.embed.embeddings)
+        layer.feature_dims = V
+        batch = data.to_device(data.SyntheticGenerator(user + item, V, series=ser, seq_len=T, seed=0).batch(B))
+        dt = timed(fwd_bwd(layer, batch, user + item + ser), 2, 10)
+        return {"config": "E DIN T=100, 50M x 32d", "B": B, "V": V, "ms_per_step": dt * 1e3, "examples_per_s": B / dt,
+                "attention_flops_factorised_fwd": 2.0 * B * 96 * 96 * 36 + 2.0 * B * T * 96 * 36}
+    raise SystemExit("unknown config %r" % name)
+
+
+if __name__ == "__main__":
+    for n in (sys.argv[1:] or ["A", "B", "C", "C26", "D", "E"]):
+        r = run(n)
+        r["n_gpus"] = 1
+        print(json.dumps(r), flush=True)

@@ -35,7 +35,8 @@ def test_argument_errors_do_not_need_a_gpu():
     assert lib.rec_emb_gather_f32(None, 10, 4, 4, None, 5, None, None, None) == -1          # null table, n > 0
     assert lib.rec_emb_gather_f32(None, 10, 4, 2, None, 0, None, None, None) == -1          # ld < E
     assert lib.rec_emb_gather_f32(None, 10, 4, 4, None, 0, None, None, None) == 0           # empty batch is a no-op
-    assert lib.rec_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, 0, None, None, 0, None, 0, 1, None, None) == -1
+    assert lib.rec_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, 0, None, None, 0, None, 0, 1, None, None,
+                            None) == -1
     assert lib.rec_dedup_workspace_bytes(0) > 0
     with pytest.raises(ValueError):
         check(-1, "x")

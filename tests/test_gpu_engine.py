@@ -22,6 +22,7 @@ def make(B, F, E, V, seed, dist):
     names = ["f%d" % i for i in range(F)]
     layers.set_init_seed(seed)
     layer = layers.DeepFMRankingLayer(feature_names=names, feature_dims=V, embedding_dims=E, mlp_dims=[32, 8]).cuda()
+    torch.manual_seed(1000 + seed)          # the random biases below must not depend on the order tests run in
     with torch.no_grad():   # non-zero biases so that every gradient path is exercised
         for n, p in layer.named_parameters():
             if "bias_" in n:
@@ -48,7 +49,10 @@ def close(a, b, tol=2e-5, floor=1e-3):
     signed terms of size ~1/B that can cancel to ~0, so the scale never drops below `floor` (i.e. an absolute 2e-8:
     a few fp32 ulps of the terms that were added)."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    return np.abs(a - b).max() <= tol * max(floor, np.abs(b).max())
+    err, scale = np.abs(a - b).max(), max(floor, np.abs(b).max())
+    if err > tol * scale:
+        print("close(): max-abs error %.3e vs scale %.3e (ratio %.2e > tol %.1e)" % (err, scale, err / scale, tol))
+    return err <= tol * scale
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
@@ -146,6 +150,7 @@ def make16(B, F, V, seed, dist):
     names = ["f%d" % i for i in range(F)]
     layers.set_init_seed(seed)
     layer = layers.DeepFMRankingLayer(feature_names=names, feature_dims=V, embedding_dims=16, mlp_dims=[32, 8]).cuda()
+    torch.manual_seed(2000 + seed)
     with torch.no_grad():
         for n, p in layer.named_parameters():
             if "bias_" in n:
