@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly (no hipGraph replay)")
     ap.add_argument("--generic", action="store_true", help="use the generic ~35-kernel step instead of the fused one")
+    ap.add_argument("--replicas", action="store_true",
+                    help="N > 1: independent full-table replicas instead of the row-sharded table + RCCL all-to-all")
+    ap.add_argument("--sharded", action="store_true", help="force the row-sharded step (the default for N > 1) at N = 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--adam-steps", type=int, default=10, help="extra: full train steps with reference-exact Adam")
@@ -123,7 +126,14 @@ def main():
     gen = data.SyntheticGenerator(names, V, dist=args.dist, seed=rank)
     n_batches = 4
     batches = [data.to_device(gen.batch(B)) for _ in range(n_batches)]
-    if args.generic:
+    sharded_mode = args.sharded or (world > 1 and not args.replicas)
+    if sharded_mode:    # table rows block-partitioned over the ranks; ids / rows / row gradients by RCCL all-to-all
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        step = engine.ShardedDeepFMStep(layer, B, gen.dims, gen.offsets)
+    elif args.generic:
         step = engine.DeepFMTrainStep(layer, B, optimizer=None, use_graph=not args.no_graph)
     else:   # 4 launches per step: fused fwd+bwd, reduction, per-column LDS sort (second stream), segment sums
         step = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, optimizer=None, use_graph=not args.no_graph)
@@ -153,8 +163,12 @@ def main():
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if int(step.oob.item()) != 0 or (hasattr(step, "bad_ids") and int(step.bad_ids.item()) != 0):
-        raise SystemExit("out-of-range id seen by the gather / sort kernels")
+    try:
+        step.check_flags() if hasattr(step, "check_flags") else None
+        if int(step.oob.item()) != 0:
+            raise IndexError("embedding id out of range")
+    except (IndexError, ValueError) as e:
+        raise SystemExit("out-of-range id seen by the gather / sort kernels: %s" % e)
     loss = float(step.loss.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
@@ -261,8 +275,16 @@ def main():
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": CFG["workload"], "vocab": V, "fields": F, "embedding_dims": E,
                           "mlp_dims": CFG["mlp_dims"], "batch_per_gpu": B, "id_distribution": args.dist,
-                          "parallelism": "1 process per GPU, independent replicas" if world > 1 else "single GPU",
-                          "hipgraph": not args.no_graph, "step": "generic" if args.generic else
+                          "parallelism": ("1 process per GPU; fused table row-sharded (block partition), batch "
+                                          "data-parallel, RCCL all-to-all of ids / rows / row gradients, flat "
+                                          "all-reduce of dense gradients") if sharded_mode else
+                          ("1 process per GPU, independent full-table replicas" if world > 1 else "single GPU"),
+                          "global_batch": world * B,
+                          "hipgraph": (not args.no_graph) and not sharded_mode,
+                          "step": "sharded, de-duplicate first: per-column sort plan (next batch, second stream), all-to-all "
+                          "of unique ids, owner gather, all-to-all of rows, fused fwd+bwd on them, per-id sums, all-to-all "
+                          "of row gradients, owner rank-merge" if sharded_mode else
+                          "generic" if args.generic else
                           "fused: fwd+bwd kernel, reduce, segment sums; de-duplication plan of batch k+1 (per-column "
                           "sort, second stream) overlaps step k"},
                "roofline": roofline, "roofline_gather": roofline_gather, "loss": loss}
@@ -270,7 +292,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, names, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

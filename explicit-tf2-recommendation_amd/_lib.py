@@ -21,6 +21,7 @@ SIGNATURES = {
     "rec_emb_fm_bwd_vals_f32": (i32, [p, i64, i64, i32, p, i64, i32, p, p, p, p, p, p]),
     "rec_dedup_workspace_bytes": (sz, [i64]),
     "rec_dedup_plan_i64": (i32, [p, i64, i64, p, p, p, p, p, sz, p]),
+    "rec_dedup_plan_sorted_lists_i64": (i32, [p, i64, p, i32, i64, p, p, p, p, p, sz, p]),
     "rec_segment_sum_workspace_bytes": (sz, [i64, i32]),
     "rec_segment_sum_f32": (i32, [p, i32, p, p, i64, i32, p, p, p]),
     "rec_gemm_f32": (i32, [i32, i32, i64, i64, i64, p, i64, p, i64, p, i64, i32, p, p, i64, p, i64, i32, p, p, p]),
@@ -42,6 +43,7 @@ SIGNATURES = {
     "rec_adam_rows_f32": (i32, [p, i64, p, p, i64, i32, p, p, p, i64, i64, f32, f32, f32, f32, p]),
     "rec_shard_bucketize_workspace_bytes": (sz, [i64, i32]),
     "rec_shard_bucketize_i64": (i32, [p, i64, i64, i32, p, p, p, p, p, sz, p]),
+    "rec_colsort_shard_map_i64": (i32, [p, p, p, p, i64, i32, i64, i32, p, p, p, p, p, p]),
     "rec_permute_rows_f32": (i32, [p, p, i64, i32, i32, p, p]),
     "rec_deepfm_fused_workspace_bytes": (sz, [i64, i32]),
     "rec_deepfm_fused_fwd_bwd_f32": (i32, [p, i64, i64, p, i32, i64, p, p, p, p, p, p, p, p, p, p, p, p, p, p, p, p, p,

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void deepfm_fwd_bwd_kernel(Cols cols, FusedArg
   float* b0s = K1s + U1 * U2;            // [32]
   float* b1s = b0s + U1;                 // [8]
   float* K2s = b1s + U2;                 // [8]
+  float* TRS = K2s + U2;                 // [4 waves][16][20]  accumulator tile transposed for 16-byte stores
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t ex0 = (int64_t)blockIdx.x * EX;
@@ -313,13 +314,22 @@ __global__ __launch_bounds__(256) void deepfm_fwd_bwd_kernel(Cols cols, FusedArg
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk + 1], bc[kk + 1], acc1, 0, 0, 0);
       }
       f32x4 acc = acc0 + acc1;
+      // accumulator tile (row = example 4g+r, col = dim l15) -> LDS -> one row quarter per lane, so that the
+      // IndexedSlices values leave as 16-byte stores (64 lanes x 16 B = sixteen full 64-B rows per instruction)
+      float* tr = TRS + wave * (16 * 20);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int e = et * 16 + 4 * g + r;
-        if (e < n_ex) {
-          float x = XT[e * XS + f * E16 + l15];
-          a.vals[((ex0 + e) * F + f) * E16 + l15] = dzs[e] * (Ss[e * E16 + l15] - x) + acc[r];
-        }
+      for (int r = 0; r < 4; ++r) tr[(4 * g + r) * 20 + l15] = acc[r];
+      const int row = lane >> 2, c4 = lane & 3;
+      float4 dx = *reinterpret_cast<const float4*>(tr + row * 20 + 4 * c4);
+      int e = et * 16 + row;
+      if (e < n_ex) {
+        const float* xp = XT + e * XS + f * E16 + 4 * c4;
+        float2 x01 = reinterpret_cast<const float2*>(xp)[0], x23 = reinterpret_cast<const float2*>(xp)[1];
+        float4 sv = *reinterpret_cast<const float4*>(Ss + e * E16 + 4 * c4);
+        float dzv = dzs[e];
+        float4 o = make_float4(dzv * (sv.x - x01.x) + dx.x, dzv * (sv.y - x01.y) + dx.y, dzv * (sv.z - x23.x) + dx.z,
+                               dzv * (sv.w - x23.y) + dx.w);
+        *reinterpret_cast<float4*>(a.vals + ((ex0 + e) * F + f) * E16 + 4 * c4) = o;
       }
     }
   }
@@ -342,24 +352,38 @@ __global__ __launch_bounds__(256) void deepfm_fwd_bwd_kernel(Cols cols, FusedArg
         if (f < F) acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[f * E16], bv, acc[f], 0, 0, 0);
     }
     __syncthreads();                                         // all reads of XT / K0s are done: reuse them as scratch
-    float* xch = XT + (nh * 64 + lane) * (4 * F + 1);        // [2][64][4F+1] <= |XT| + |K0s| for every F
-    if (et == 1) {
+    // the two example tiles of a unit half add up: tile 0's wave finalises fields [0, Fh), tile 1's wave [Fh, F);
+    // each first hands the other half of its accumulators over through LDS
+    const int Fh = (F + 1) / 2;
+    const int xs = 4 * Fh + 1;
+    float* mine = XT + (wave * 64 + lane) * xs;                       // written by me, read by my partner
+    const float* theirs = XT + ((wave ^ 2) * 64 + lane) * xs;         // partner = same nh, other example tile
 #pragma unroll
-      for (int f = 0; f < MAXF; ++f)
-        if (f < F) {
+    for (int f = 0; f < MAXF; ++f) {
+      bool give = et == 0 ? (f >= Fh && f < F) : (f < Fh);
+      if (give) {
+        int slot = et == 0 ? f - Fh : f;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) xch[f * 4 + r] = acc[f][r];
-        }
+        for (int r = 0; r < 4; ++r) mine[slot * 4 + r] = acc[f][r];
+      }
     }
     __syncthreads();
-    if (et == 0) {
+    float* tr = TRS + wave * (16 * 20);
+    const int row = lane >> 2, c4 = lane & 3;
 #pragma unroll
-      for (int f = 0; f < MAXF; ++f)
-        if (f < F) {
+    for (int f = 0; f < MAXF; ++f) {
+      bool keep = et == 0 ? (f < Fh) : (f >= Fh && f < F);
+      if (keep) {
+        int slot = et == 0 ? f : f - Fh;
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            part[(f * E16 + 4 * g + r) * U1 + nh * 16 + l15] = acc[f][r] + xch[f * 4 + r];
+        for (int r = 0; r < 4; ++r) {
+          float t0 = et == 0 ? acc[f][r] : theirs[slot * 4 + r];      // tile 0's term first: fixed order
+          float t1 = et == 0 ? theirs[slot * 4 + r] : acc[f][r];
+          tr[(4 * g + r) * 20 + l15] = t0 + t1;                        // (row = dim 4g+r, col = unit l15)
         }
+        float4 o = *reinterpret_cast<const float4*>(tr + row * 20 + 4 * c4);   // one row quarter per lane
+        *reinterpret_cast<float4*>(part + (f * E16 + row) * U1 + nh * 16 + 4 * c4) = o;
+      }
     }
   }
 }
@@ -424,7 +448,9 @@ __global__ __launch_bounds__(1024) void deepfm_reduce_kernel(const float* __rest
 size_t fused_lds_bytes(int F) {
   size_t D = (size_t)F * E16;
   size_t f = (size_t)EX * (D + 2) + D * HS + 2 * (size_t)EX * HS + (size_t)EX * E16 + 2 * (size_t)EX * U2 +
-             3 * (size_t)EX + U1 * U2 + U1 + 2 * U2;
+             3 * (size_t)EX + U1 * U2 + U1 + 2 * U2 + 4 * 16 * 20;
+  size_t xch = 256 * (4 * (size_t)((F + 1) / 2) + 1);      // P6 exchange scratch aliases the front of the LDS
+  if (f < xch) f = xch;
   return f * sizeof(float);
 }
 

@@ -34,26 +34,57 @@ __global__ __launch_bounds__(256) void shard_count_kernel(const int64_t* __restr
   if (threadIdx.x < n_shard) tile_counts[(int64_t)blockIdx.x * n_shard + threadIdx.x] = cnt[threadIdx.x];
 }
 
-// single workgroup: column-wise exclusive scan of tile_counts[n_tiles][n_shard] + shard bases
-__global__ __launch_bounds__(64) void shard_scan_kernel(int32_t* __restrict__ tile_counts, int n_tiles, int n_shard,
-                                                        int64_t* __restrict__ send_counts) {
+// single workgroup of 1024 threads: column-wise exclusive scan of tile_counts[n_tiles][n_shard] + shard bases.
+// Thread t owns tile (pass*1024 + t); one block scan per shard and pass, carries in LDS.
+__global__ __launch_bounds__(1024) void shard_scan_kernel(int32_t* __restrict__ tile_counts, int n_tiles, int n_shard,
+                                                          int64_t* __restrict__ send_counts) {
   __shared__ int64_t tot[MAX_SHARD];
-  int s = threadIdx.x;
-  int64_t run = 0;
-  if (s < n_shard) {
-    for (int t = 0; t < n_tiles; ++t) run += tile_counts[(int64_t)t * n_shard + s];
-    tot[s] = run;
-    send_counts[s] = run;
+  __shared__ int wsum[16];
+  __shared__ int64_t carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // totals per shard
+  for (int s = 0; s < n_shard; ++s) {
+    int v = 0;
+    for (int t = tid; t < n_tiles; t += 1024) v += tile_counts[(int64_t)t * n_shard + s];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if (lane == 0) wsum[wave] = v;
+    __syncthreads();
+    if (tid == 0) {
+      int64_t a = 0;
+      for (int q = 0; q < 16; ++q) a += wsum[q];
+      tot[s] = a;
+      send_counts[s] = a;
+    }
   }
   __syncthreads();
-  if (s < n_shard) {
-    int64_t base = 0;
-    for (int q = 0; q < s; ++q) base += tot[q];
-    int64_t acc = base;
-    for (int t = 0; t < n_tiles; ++t) {
-      int c = tile_counts[(int64_t)t * n_shard + s];
-      tile_counts[(int64_t)t * n_shard + s] = (int32_t)acc;  // now an offset
-      acc += c;
+  for (int s = 0; s < n_shard; ++s) {
+    if (tid == 0) {
+      int64_t base = 0;
+      for (int q = 0; q < s; ++q) base += tot[q];
+      carry = base;
+    }
+    __syncthreads();
+    for (int t0 = 0; t0 < n_tiles; t0 += 1024) {
+      int t = t0 + tid;
+      int c = t < n_tiles ? tile_counts[(int64_t)t * n_shard + s] : 0;
+      int incl = c;
+      for (int o = 1; o < 64; o <<= 1) {
+        int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+      }
+      if (lane == 63) wsum[wave] = incl;
+      __syncthreads();
+      int woff = 0, all = 0;
+      for (int q = 0; q < 16; ++q) {
+        if (q < wave) woff += wsum[q];
+        all += wsum[q];
+      }
+      int64_t base = carry;
+      if (t < n_tiles) tile_counts[(int64_t)t * n_shard + s] = (int32_t)(base + woff + incl - c);   // now an offset
+      __syncthreads();
+      if (tid == 0) carry = base + all;
+      __syncthreads();
     }
   }
 }
@@ -117,6 +148,58 @@ __global__ __launch_bounds__(256) void permute_rows_kernel(const float* __restri
   else out[t] = in[p * E + d];
 }
 
+// ---- de-duplicate-first exchange plan.  Input: the per-column sort plan of a batch (rec_colsort_plan_i64; columns own
+// ascending id ranges, so the concatenation of the columns' unique ids is globally ascending and, with the block
+// partition, already grouped by owner).  One thread per (column, sorted position):
+//   uidx[f][example]   = compact index of the lookup's id in that ascending list   (what the fused kernel gathers by)
+//   uid_local[compact] = id - owner*rows_per_shard                                   (what is sent to the owner)
+//   send_counts[owner] = unique ids of this batch owned by `owner`                  (integer atomics: exact)
+__global__ __launch_bounds__(256) void shard_map_kernel(const int32_t* __restrict__ perm, const int64_t* __restrict__ col_uid,
+                                                        const int32_t* __restrict__ col_seg, const int32_t* __restrict__ col_nu,
+                                                        int64_t B, int F, int64_t rows_per_shard, int n_shard,
+                                                        int64_t* __restrict__ uid_local, int64_t* __restrict__ uidx,
+                                                        unsigned long long* __restrict__ send_counts,
+                                                        int64_t* __restrict__ n_uniq, int* __restrict__ oob) {
+  __shared__ int nu_s[REC_MAX_COLS];
+  __shared__ int cnt[MAX_SHARD];
+  const int tid = threadIdx.x;
+  if (tid < F) nu_s[tid] = col_nu[tid];
+  if (tid < MAX_SHARD) cnt[tid] = 0;
+  __syncthreads();
+  const int64_t t = (int64_t)blockIdx.x * 256 + tid;
+  const int f = (int)(t / B);
+  const int s = (int)(t - (int64_t)f * B);
+  if (f < F) {
+    int64_t before = 0, total = 0;
+    for (int q = 0; q < F; ++q) {
+      if (q < f) before += nu_s[q];
+      total += nu_s[q];
+    }
+    const int nu = nu_s[f];
+    const int32_t* seg = col_seg + (int64_t)f * (B + 1);
+    int lo = 0, hi = nu - 1;                       // largest u with seg[u] <= s   (seg[0] = 0)
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (seg[mid] <= s) lo = mid; else hi = mid - 1;
+    }
+    uidx[(int64_t)f * B + perm[(int64_t)f * B + s]] = before + lo;
+    if (seg[lo] == s) {                            // run head: one thread per unique id
+      int64_t id = col_uid[(int64_t)f * B + lo];
+      int64_t o = id >= 0 ? id / rows_per_shard : -1;
+      if (o < 0 || o >= n_shard) {
+        if (oob) *oob = 1;
+        o = 0;
+      } else {
+        atomicAdd(&cnt[(int)o], 1);
+      }
+      uid_local[before + lo] = id - o * rows_per_shard;
+    }
+    if (t == 0) *n_uniq = total;
+  }
+  __syncthreads();
+  if (tid < n_shard && cnt[tid]) atomicAdd(&send_counts[tid], (unsigned long long)cnt[tid]);
+}
+
 }  // namespace
 
 extern "C" size_t rec_shard_bucketize_workspace_bytes(int64_t n, int n_shard) {
@@ -138,7 +221,7 @@ extern "C" int rec_shard_bucketize_i64(const int64_t* ids, int64_t n, int64_t ro
   hipLaunchKernelGGL(shard_count_kernel, dim3(n_tiles), dim3(256), 0, st, ids, n, rows_per_shard, n_shard, tile_counts,
                      oob_flag);
   REC_LAUNCH_CHECK();
-  hipLaunchKernelGGL(shard_scan_kernel, dim3(1), dim3(64), 0, st, tile_counts, n_tiles, n_shard, send_counts);
+  hipLaunchKernelGGL(shard_scan_kernel, dim3(1), dim3(1024), 0, st, tile_counts, n_tiles, n_shard, send_counts);
   REC_LAUNCH_CHECK();
   hipLaunchKernelGGL(shard_scatter_kernel, dim3(n_tiles), dim3(256), 0, st, ids, n, rows_per_shard, n_shard,
                      tile_counts, perm, local_ids);
@@ -152,6 +235,24 @@ extern "C" int rec_permute_rows_f32(const float* in, const int64_t* perm, int64_
   if (n == 0) return REC_OK;
   hipLaunchKernelGGL(permute_rows_kernel, dim3((unsigned)ceil_div64(n * E, 256)), dim3(256), 0, as_stream(stream), in,
                      perm, n, E, scatter, out);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_colsort_shard_map_i64(const int32_t* perm, const int64_t* col_uid, const int32_t* col_seg,
+                                         const int32_t* col_nu, int64_t B, int F, int64_t rows_per_shard, int n_shard,
+                                         int64_t* uid_local, int64_t* uidx, int64_t* send_counts, int64_t* n_uniq,
+                                         int* oob_flag, void* stream) {
+  if (!perm || !col_uid || !col_seg || !col_nu || !uid_local || !uidx || !send_counts || !n_uniq || B <= 0 || F <= 0 ||
+      rows_per_shard <= 0 || n_shard <= 0)
+    return REC_E_ARG;
+  if (n_shard > MAX_SHARD || F > REC_MAX_COLS) return REC_E_UNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(send_counts, 0, sizeof(int64_t) * n_shard, st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(shard_map_kernel, dim3((unsigned)ceil_div64(B * F, 256)), dim3(256), 0, st, perm, col_uid, col_seg,
+                     col_nu, B, F, rows_per_shard, n_shard, uid_local, uidx, (unsigned long long*)send_counts, n_uniq,
+                     oob_flag);
   REC_LAUNCH_CHECK();
   return REC_OK;
 }

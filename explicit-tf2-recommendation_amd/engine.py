@@ -433,3 +433,257 @@ class DeepFMFusedStep:
         out["embed.embeddings"] = (self.uniq_ids, self.g_embed_rows, self.n_uniq)
         out["w.embeddings"] = (self.uniq_ids, self.g_w_rows, self.n_uniq)
         return out
+
+
+class _HostCounts:
+    """[2,P] split sizes on their way to the host: pinned copy + event, read when the step that needs them starts."""
+
+    def __init__(self, dev_counts):
+        self.host = torch.empty(tuple(dev_counts.shape), dtype=dev_counts.dtype, pin_memory=True)
+        self.host.copy_(dev_counts, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def get(self):
+        self.event.synchronize()
+        both = self.host.tolist()
+        return both[0], both[1]
+
+
+class HipStepBackend:
+    """Device-side pieces of ShardedDeepFMStep, all HIP kernels on preallocated buffers.  The CPU gloo test
+    (tests/test_sharded.py) injects an oracle-backed stand-in with the same methods to exercise the exchange logic
+    without a GPU; the product never does."""
+
+    def __init__(self, step, field_dims, field_offsets):
+        self.step = step
+        B, F, P = step.B, step.F, step.P
+        dev = step.dev
+        n = B * F
+        self.max_key = max(int(d) for d in field_dims) - 1
+        if _bits(self.max_key + 1) + _bits(B) > 32 or ((self.max_key << _bits(B)) | (B - 1)) >= 0xFFFFFFFF:
+            raise NotImplementedError("field too wide for the 32-bit sort words at this batch size")
+        if any(field_offsets[i] >= field_offsets[i + 1] for i in range(F - 1)):
+            raise ValueError("field offsets must be ascending (DataGenerator contract)")
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        i64 = dict(dtype=torch.int64, device=dev)
+        self.col_lo = torch.tensor([int(o) for o in field_offsets], **i64)
+        self.bad_ids = torch.zeros(1, **i32)
+        self.plans = [dict(perm=torch.empty((F, B), **i32), col_uid=torch.empty((F, B), **i64),
+                           col_seg=torch.empty((F, B + 1), **i32), col_nu=torch.zeros(F, **i32),
+                           uid_local=torch.empty(n, **i64), uidx=torch.empty((F, B), **i64),
+                           counts=torch.zeros(P, **i64), recv=torch.zeros(P, **i64),
+                           n_uniq=torch.zeros(1, **i64)) for _ in range(2)]
+        self.sort_ws = [torch.empty(lib.rec_colsort_workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+                        for _ in range(2)]
+        self.gz = torch.empty(B, **f32)
+        self.vals = torch.empty((n, 16), **f32)
+        self.uniq_ids = torch.empty(n, **i64)
+        self.ge = torch.empty((n, 16), **f32)
+        self.gw = torch.empty((n, 1), **f32)
+        self.n_uniq = torch.zeros(1, **i64)
+        self.ws = torch.empty(lib.rec_deepfm_fused_workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+        self.side = torch.cuda.Stream(device=dev)
+
+    # -- streams: the plan of the next batch depends on ids only and is built beside the current step
+    def fork(self):
+        self.side.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self.side)
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.side)
+
+    def plan(self, cols, buf):
+        """Per-column sort + unique (rec_colsort_plan_i64), then the exchange map (rec_colsort_shard_map_i64)."""
+        st_ = self.step
+        B, F = st_.B, st_.F
+        pl = self.plans[buf]
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        arr = (C.c_void_p * F)(*[c.data_ptr() for c in cols])
+        check(lib.rec_colsort_plan_i64(arr, F, B, st_.V, _p(self.col_lo), self.max_key, _p(pl["perm"]),
+                                       _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.bad_ids),
+                                       _p(self.sort_ws[buf]), st), "rec_colsort_plan_i64")
+        check(lib.rec_colsort_shard_map_i64(_p(pl["perm"]), _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), B, F,
+                                            st_.rows_per_shard, st_.P, _p(pl["uid_local"]), _p(pl["uidx"]),
+                                            _p(pl["counts"]), _p(pl["n_uniq"]), _p(st_.oob), st),
+              "rec_colsort_shard_map_i64")
+        return pl
+
+    counts_to_host = staticmethod(_HostCounts)
+    gather = staticmethod(ops.emb_gather)
+
+    def rows_step(self, pl, rows_local, y):
+        """The fused forward+backward kernel on the exchanged rows: the local [n_uniq,32] buffer is the "table" and
+        the ids are the compact indices uidx.  Fills step.g / step.loss; returns (vals [n,16], gz [B])."""
+        st_ = self.step
+        L, B, F, g = st_.layer, st_.B, st_.F, st_.g
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        arr = (C.c_void_p * F)(*[pl["uidx"][f].data_ptr() for f in range(F)])
+        check(lib.rec_deepfm_fused_fwd_bwd_f32(
+            _p(rows_local), 32, rows_local.shape[0], arr, F, B, _p(L.bias), _p(L.MLP_layer1.kernel_0),
+            _p(L.MLP_layer1.bias_0), _p(L.MLP_layer1.kernel_1), _p(L.MLP_layer1.bias_1), _p(L.MLP_layer2.kernel_0),
+            _p(L.MLP_layer2.bias_0), _p(y), _p(self.gz), _p(self.vals), None, _p(g["MLP_layer1.kernel_0"]),
+            _p(g["MLP_layer1.bias_0"]), _p(g["MLP_layer1.kernel_1"]), _p(g["MLP_layer1.bias_1"]),
+            _p(g["MLP_layer2.kernel_0"]), _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(st_.loss), _p(st_.oob),
+            _p(self.ws), st), "rec_deepfm_fused_fwd_bwd_f32")
+        return self.vals, self.gz
+
+    def local_grad(self, pl, vals, gz):
+        """This batch's gradient per unique id (embed [n,16], w [n,1]; first n_uniq rows, ascending id = send order)."""
+        st_ = self.step
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.rec_colseg_sum_f32(_p(vals), _p(gz), _p(pl["perm"]), _p(pl["col_uid"]), _p(pl["col_seg"]),
+                                     _p(pl["col_nu"]), st_.B, st_.F, _p(self.uniq_ids), _p(self.ge), _p(self.gw),
+                                     _p(self.n_uniq), st), "rec_colseg_sum_f32")
+        return self.ge, self.gw
+
+    def owner_reduce(self, their_ids, recv_counts, ge_theirs, gw_theirs, scale):
+        """Union of the P ascending id lists that arrived + row sums in list order, times ``scale``."""
+        plan = ops.DedupPlan(their_ids, self.step.rows_per_shard, list_counts=recv_counts)
+        ge, gw = plan.segment_sum(ge_theirs, 16), plan.segment_sum(gw_theirs, 1)
+        if scale != 1.0:
+            ops.axpby(scale, ge, 0.0, ge)
+            ops.axpby(scale, gw, 0.0, gw)
+        return plan.uniq_ids, ge, gw, plan.n_uniq
+
+    def check_flags(self):
+        if int(self.bad_ids.item()) != 0:
+            raise ValueError("an id lies outside its field's [offset, offset+dim) range (DataGenerator contract)")
+
+
+class ShardedDeepFMStep:
+    """DeepFM train_loop iteration with the fused [embed|w|pad] table ROW-SHARDED over the ranks of a process group
+    (SURVEY.md section 8e): data-parallel batch (every rank its own B examples), block partition
+    ``owner = id // ceil(V/P)``.  De-duplicate first, then exchange:
+
+        plan (ids only; built for batch k+1 on a second stream while batch k is differentiated)
+            per-column sort + unique  ->  the batch's unique ids, ascending = already grouped by owner
+            C0  all-to-all of the per-owner unique-id counts; both count vectors travel to the host asynchronously
+        C1  all-to-all of the unique local ids                              (RCCL; "nccl" backend on ROCm)
+        --  owner-side gather of the 128-byte fused rows                    (HIP, ids ascending)
+        C2  all-to-all of the rows back -> a local [n_uniq, 32] table in id order: no permutation anywhere
+        --  the fused forward+backward kernel on those rows (it gathers by the compact index of each lookup),
+            then the per-unique-id segment sums of the row gradients (embed 16 + w 1), in send order
+        C3  all-to-all of the summed row gradients to the owners, who merge the P ascending lists (rank merge)
+        C4  one flat all-reduce (SUM) of the dense gradients and the loss, divided by P
+
+    The loss is the mean over the GLOBAL batch of P*B examples (2.FM/ModelManager.py:171-177 on the concatenated
+    batch): every rank's kernel scales by 1/B, so dense gradients are averaged over ranks and owner-side row sums
+    are multiplied by 1/P.  Same kernels as the single-GPU path; at world_size 1 it reproduces DeepFMFusedStep and at
+    world_size 2 (gloo) the global-batch result (tests/test_sharded.py).
+    ``table_shard`` [rows_per_shard, 32] holds global rows [rank*rows_per_shard, ...).
+    """
+
+    def __init__(self, layer, batch_size, field_dims, field_offsets, group=None, backend=None, comm=None):
+        from . import sharded
+        self.comm = comm if comm is not None else sharded.DistComm(group)
+        self.P, self.rank = self.comm.world, self.comm.rank
+        self.layer = layer
+        self.B = B = int(batch_size)
+        self.F = F = len(layer.feature_names)
+        emb, w = layer.embed.embeddings, layer.w.embeddings
+        V, E = emb.shape
+        if E != 16 or list(layer.mlp_dims) != [32, 8]:
+            raise NotImplementedError("sharded step: embedding_dims=16, mlp_dims=[32,8]")
+        if F > 28 or B > 16384 or len(field_dims) != F or len(field_offsets) != F:
+            raise NotImplementedError("sharded step: F <= 28, B <= 16384, one (dim, offset) per feature")
+        fused = getattr(layer, "_fused_storage", None)      # [V,32] rows = [embed | w | pad] (layers._FMTables)
+        if fused is None:                                   # layer not on the GPU (CPU exchange-logic test)
+            fused = torch.zeros((V, 32), dtype=torch.float32, device=emb.device)
+            fused[:, :16].copy_(emb.data)
+            fused[:, 16:17].copy_(w.data)
+        self.V = V
+        self.rows_per_shard = -(-V // self.P)
+        lo = min(V, self.rank * self.rows_per_shard)
+        hi = min(V, lo + self.rows_per_shard)
+        self.row_range = (lo, hi)
+        self.dev = dev = emb.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        # this rank's block of the fused table (a real deployment would never hold the full table anywhere)
+        self.table_shard = torch.zeros((self.rows_per_shard, 32), **f32)
+        self.table_shard[: hi - lo].copy_(fused[lo:hi])
+        self.n = B * F
+        self.loss = torch.empty(1, **f32)
+        self.oob = torch.zeros(1, dtype=torch.int32, device=dev)
+        D = F * 16
+        self.g = {
+            "MLP_layer1.kernel_0": torch.empty((D, 32), **f32), "MLP_layer1.bias_0": torch.empty(32, **f32),
+            "MLP_layer1.kernel_1": torch.empty((32, 8), **f32), "MLP_layer1.bias_1": torch.empty(8, **f32),
+            "MLP_layer2.kernel_0": torch.empty((8, 1), **f32), "MLP_layer2.bias_0": torch.empty(1, **f32),
+            "bias": torch.empty(1, **f32),
+        }
+        self.be = (backend or HipStepBackend)(self, field_dims, field_offsets)
+        self._next = None               # (key, buffer, plan) announced by the previous call
+        self.table_grad = None          # (local uniq ids, embed rows [.,16], w rows [.,1], n_uniq) after a step
+
+    def _cols(self, inputs):
+        cols = []
+        for name in self.layer.feature_names:
+            c = inputs[name]
+            if c.dtype != torch.int64 or c.numel() != self.B or not c.is_contiguous():
+                raise ValueError("feature %r must be a contiguous int64 tensor with %d ids" % (name, self.B))
+            cols.append(c)
+        return cols
+
+    def _finish_plan(self, pl):
+        """C0 + the asynchronous hand-over of both split-size vectors to the host."""
+        recv = self.comm.exchange_counts(pl["counts"])
+        if pl.get("recv") is not None:
+            pl["recv"].copy_(recv)                           # preallocated: outlives the stream it was produced on
+        else:
+            pl["recv"] = recv
+        pl["host"] = self.be.counts_to_host(torch.stack([pl["counts"], recv]))
+
+    def __call__(self, inputs, label_name="label", next_inputs=None):
+        be, comm = self.be, self.comm
+        cols = self._cols(inputs)
+        y = inputs[label_name]
+        key = tuple(c.data_ptr() for c in cols)
+        if self._next is not None and self._next[0] == key:
+            _, buf, pl = self._next
+            be.join()                                        # the plan was built on the second stream
+        else:
+            buf = 0
+            pl = be.plan(cols, buf)
+            self._finish_plan(pl)
+        self._next = None
+        nxt = None
+        if next_inputs is not None:
+            next_cols = self._cols(next_inputs)
+            with be.fork():
+                nxt = be.plan(next_cols, 1 - buf)            # kernels only; its count exchange is issued below
+        send, recv = pl["host"].get()                        # split sizes (already on the host when pipelined)
+        nu = sum(send)
+        their_ids = comm.all_to_all(pl["uid_local"][:nu], send, recv)          # C1
+        rows_out = be.gather(self.table_shard, their_ids)                      # owner-side gather of 128-B rows
+        rows_local = comm.all_to_all(rows_out, recv, send)                     # C2: [n_uniq, 32] in ascending id order
+        if nxt is not None:
+            with be.fork():
+                self._finish_plan(nxt)                       # C0 of the next batch rides behind C2 on the RCCL stream
+            self._next = (tuple(c.data_ptr() for c in next_cols), 1 - buf, nxt)
+        vals, gz = be.rows_step(pl, rows_local, y)
+        ge, gw = be.local_grad(pl, vals, gz)
+        ge_theirs = comm.all_to_all(ge[:nu], send, recv)                       # C3
+        gw_theirs = comm.all_to_all(gw[:nu], send, recv)
+        if their_ids.numel():
+            self.table_grad = be.owner_reduce(their_ids, pl["recv"], ge_theirs, gw_theirs, 1.0 / self.P)
+        else:
+            self.table_grad = None
+        # C4: dense gradients and the loss, one flat all-reduce (mean over ranks = the global-batch gradient)
+        if self.P > 1:
+            g = self.g
+            flat = torch.cat([t.reshape(-1) for t in g.values()] + [self.loss])
+            comm.all_reduce_sum(flat)
+            flat /= self.P
+            off = 0
+            for t in list(g.values()) + [self.loss]:
+                k = t.numel()
+                t.copy_(flat[off:off + k].reshape(t.shape))
+                off += k
+        return self.loss
+
+    def check_flags(self):
+        if int(self.oob.item()) != 0:
+            raise IndexError("embedding id out of range [0, feature_dims)")
+        self.be.check_flags()

@@ -126,9 +126,13 @@ def emb_fm_bwd_vals(embed, X, gz, sumvec, rows=None, extra=None):
 # ---------------------------------------------------------------------------------------------------
 
 class DedupPlan:
-    """Sorted-unique plan of a flat id list; reusable for every table indexed by the same ids."""
+    """Sorted-unique plan of a flat id list; reusable for every table indexed by the same ids.
 
-    def __init__(self, ids, V):
+    ``list_counts`` (int64 device tensor [P]): the ids are P ascending duplicate-free lists laid end to end (what P
+    requesters send to a shard owner after de-duplicating their own batches); the plan is then a rank merge instead
+    of a radix sort (rec_dedup_plan_sorted_lists_i64)."""
+
+    def __init__(self, ids, V, list_counts=None):
         ids = _i64(ids.reshape(-1), "ids")
         n = ids.numel()
         dev = ids.device
@@ -139,8 +143,15 @@ class DedupPlan:
         self.n_uniq = torch.empty(1, dtype=torch.int64, device=dev)
         nbytes = lib.rec_dedup_workspace_bytes(n)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        check(lib.rec_dedup_plan_i64(_ptr(ids), n, V, _ptr(self.uniq_ids), _ptr(self.seg_start), _ptr(self.perm),
-                                     _ptr(self.n_uniq), _ptr(ws), nbytes, _stream()), "rec_dedup_plan_i64")
+        if list_counts is None:
+            check(lib.rec_dedup_plan_i64(_ptr(ids), n, V, _ptr(self.uniq_ids), _ptr(self.seg_start), _ptr(self.perm),
+                                         _ptr(self.n_uniq), _ptr(ws), nbytes, _stream()), "rec_dedup_plan_i64")
+        else:
+            lc = _i64(list_counts.reshape(-1), "list_counts")
+            check(lib.rec_dedup_plan_sorted_lists_i64(_ptr(ids), n, _ptr(lc), lc.numel(), V, _ptr(self.uniq_ids),
+                                                      _ptr(self.seg_start), _ptr(self.perm), _ptr(self.n_uniq),
+                                                      _ptr(ws), nbytes, _stream()),
+                  "rec_dedup_plan_sorted_lists_i64")
 
     def segment_sum(self, vals, E, row_div=1):
         """vals [n/row_div, E] -> [n, E]; rows >= n_uniq are zero."""

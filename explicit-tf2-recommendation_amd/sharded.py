@@ -62,6 +62,10 @@ class DistComm:
         dist.all_to_all_single(out, x, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
         return out
 
+    def all_reduce_sum(self, x):
+        dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+        return x
+
 
 class _Lookup(torch.autograd.Function):
     @staticmethod

@@ -95,6 +95,13 @@ int rec_dedup_plan_i64(const int64_t* ids, int64_t n, int64_t V, int64_t* uniq_i
 /* out[u,:] = sum over s in [seg_start[u], seg_start[u+1]) of vals[perm[s] / row_div, :]   for u in [0,n).
  * row_div = 1 for per-lookup values; row_div = F broadcasts a per-example value (the w table, whose
  * per-lookup gradient is gz[b]). */
+/* Same outputs as rec_dedup_plan_i64 for ids that arrive as n_lists ascending, duplicate-free lists laid end to end
+ * (list_counts [n_lists], int64, on the device; their sum must be n): the owner-side union of what P requesters
+ * send after de-duplicating their own batches.  Rank merge by binary search instead of a sort; rows of one id are
+ * summed in list order.  workspace: rec_dedup_workspace_bytes(n). */
+int rec_dedup_plan_sorted_lists_i64(const int64_t* ids, int64_t n, const int64_t* list_counts, int n_lists,
+                                    int64_t V, int64_t* uniq_ids, int32_t* seg_start, int32_t* perm,
+                                    int64_t* n_uniq, void* workspace, size_t workspace_bytes, void* stream);
 size_t rec_segment_sum_workspace_bytes(int64_t n, int E);
 int rec_segment_sum_f32(const float* vals, int E, const int32_t* perm, const int32_t* seg_start, int64_t n,
                         int32_t row_div, float* out, float* workspace, void* stream);
@@ -176,6 +183,14 @@ size_t rec_shard_bucketize_workspace_bytes(int64_t n, int n_shard);
 int rec_shard_bucketize_i64(const int64_t* ids, int64_t n, int64_t rows_per_shard, int n_shard,
                             int64_t* perm, int64_t* send_counts, int64_t* local_ids, int* oob_flag,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* De-duplicate-first exchange plan on top of rec_colsort_plan_i64 (columns own ascending id ranges => the batch's
+ * unique ids, column after column, are globally ascending and grouped by owner): uidx [F,B] = compact index of every
+ * lookup's id in that list (the fused kernel gathers the exchanged rows by it), uid_local [B*F] = id - owner *
+ * rows_per_shard (first *n_uniq valid), send_counts [n_shard] (int64) = unique ids per owner. */
+int rec_colsort_shard_map_i64(const int32_t* perm, const int64_t* col_uid, const int32_t* col_seg,
+                              const int32_t* col_nu, int64_t B, int F, int64_t rows_per_shard, int n_shard,
+                              int64_t* uid_local, int64_t* uidx, int64_t* send_counts, int64_t* n_uniq,
+                              int* oob_flag, void* stream);
 /* out[perm[i], :] = in[i, :]   (inverse permutation of received rows) and its transpose */
 int rec_permute_rows_f32(const float* in, const int64_t* perm, int64_t n, int E, int scatter, float* out,
                          void* stream);

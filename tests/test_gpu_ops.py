@@ -363,6 +363,100 @@ def test_shard_bucketize_bit_exact(ops, P, zipf):
     assert np.array_equal(back, tab[ids])
 
 
+def test_shard_bucketize_many_tiles(ops):
+    """> 1024 tiles of 1024 ids: the single-workgroup scan runs several passes with a carry."""
+    V, n, P = 10_000_019, 1_300_000, 8
+    ids = H.rng(77).integers(0, V, size=n)
+    rows_per = -(-V // P)
+    perm, counts, local = ops.shard_bucketize(dev(ids), rows_per, P)
+    rp, rc, rl = L.shard_bucketize(ids, rows_per, P)
+    assert np.array_equal(counts.cpu().numpy(), rc)
+    assert np.array_equal(perm.cpu().numpy(), rp) and np.array_equal(local.cpu().numpy(), rl)
+
+
+@pytest.mark.parametrize("P", [1, 2, 8, 64])
+@pytest.mark.parametrize("overlap", ["heavy", "none", "ragged"])
+def test_dedup_plan_sorted_lists(ops, P, overlap):
+    """Owner-side union of P ascending duplicate-free lists (rank merge): ids bit exact, sums in list order."""
+    r = H.rng(1000 + P)
+    V, E = 50_000, 16
+    lists = []
+    for q in range(P):
+        if overlap == "heavy":
+            k = 3000
+            pool = V // 10
+        elif overlap == "none":
+            k = 500
+            pool = V
+        else:
+            k = [0, 1, 4000, 17][q % 4]
+            pool = V // 4
+        ids = np.sort(r.choice(pool, size=k, replace=False)).astype(np.int64)
+        if overlap == "none":
+            ids = ids // P * P + q if P <= 8 else ids          # disjoint residues for small P
+            ids = np.unique(ids)
+        lists.append(ids)
+    counts = np.array([len(x) for x in lists], np.int64)
+    ids = np.concatenate(lists) if counts.sum() else np.zeros(0, np.int64)
+    n = ids.size
+    if n == 0:
+        pytest.skip("empty union")
+    vals = r.normal(size=(n, E)).astype(np.float32)
+    plan = ops.DedupPlan(dev(ids), V, list_counts=dev(counts))
+    nu = int(plan.n_uniq.item())
+    uniq_ref, sum_ref = L.dedup_indexed_slices(ids, vals.astype(np.float64), "sorted")
+    assert nu == uniq_ref.size and np.array_equal(plan.uniq_ids.cpu().numpy()[:nu], uniq_ref)
+    perm, seg = plan.perm.cpu().numpy(), plan.seg_start.cpu().numpy()
+    assert sorted(perm.tolist()) == list(range(n)) and np.all(np.diff(ids[perm]) >= 0)
+    for u in range(0, nu, max(1, nu // 200)):                       # members of a run in list (= position) order
+        assert np.all(np.diff(perm[seg[u]:seg[u + 1]]) > 0)
+    out = plan.segment_sum(dev(vals), E).cpu().numpy()
+    assert np.abs(out[:nu] - sum_ref).max() <= 1e-5 * max(1, np.abs(sum_ref).max())
+    assert np.all(out[nu:] == 0)
+    # the radix-sort plan of the same ids gives the same unique list and the same sums bit for bit (same order)
+    plan2 = ops.DedupPlan(dev(ids), V)
+    assert np.array_equal(plan2.uniq_ids.cpu().numpy()[:nu], uniq_ref)
+    assert np.array_equal(plan2.segment_sum(dev(vals), E).cpu().numpy(), out)
+
+
+@pytest.mark.parametrize("P", [1, 2, 8])
+@pytest.mark.parametrize("B,F,zipf", [(8192, 26, None), (1000, 26, 1.05), (33, 3, 1.2), (4096, 5, 1.05)])
+def test_colsort_shard_map(ops, P, B, F, zipf):
+    """De-duplicate-first exchange map over the per-column sort plan: compact indices, local ids and per-owner counts
+    are integer work -- bit exact against numpy.unique."""
+    import ctypes as C
+    from explicit_tf2_recommendation_amd._lib import lib, check
+    V = 1_000_003
+    X = field_ids(5 + P, B, F, V, zipf)
+    dims = [V // F] * F
+    dims[-1] += V - sum(dims)
+    off = np.concatenate([[0], np.cumsum(dims)[:-1]]).astype(np.int64)
+    cols = [dev(X[:, f]) for f in range(F)]
+    i32 = dict(dtype=torch.int32, device="cuda")
+    i64 = dict(dtype=torch.int64, device="cuda")
+    perm, col_uid = torch.empty((F, B), **i32), torch.empty((F, B), **i64)
+    col_seg, col_nu = torch.empty((F, B + 1), **i32), torch.zeros(F, **i32)
+    bad, oob = torch.zeros(1, **i32), torch.zeros(1, **i32)
+    ws = torch.empty(lib.rec_colsort_workspace_bytes(B, F), dtype=torch.uint8, device="cuda")
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    arr = (C.c_void_p * F)(*[c.data_ptr() for c in cols])
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(lib.rec_colsort_plan_i64(arr, F, B, V, vp(dev(off)), max(dims) - 1, vp(perm), vp(col_uid), vp(col_seg),
+                                   vp(col_nu), vp(bad), vp(ws), st), "rec_colsort_plan_i64")
+    rps = -(-V // P)
+    uid_local, uidx = torch.full((B * F,), -1, **i64), torch.full((F, B), -1, **i64)
+    counts, n_uniq = torch.full((P,), 99, **i64), torch.zeros(1, **i64)
+    check(lib.rec_colsort_shard_map_i64(vp(perm), vp(col_uid), vp(col_seg), vp(col_nu), B, F, rps, P, vp(uid_local),
+                                        vp(uidx), vp(counts), vp(n_uniq), vp(oob), st), "rec_colsort_shard_map_i64")
+    uid, inv = np.unique(X, return_inverse=True)
+    nu = int(n_uniq.item())
+    assert nu == uid.size and bad.item() == 0 and oob.item() == 0
+    owner = uid // rps
+    assert np.array_equal(uid_local.cpu().numpy()[:nu], uid - owner * rps)
+    assert np.array_equal(uidx.cpu().numpy(), inv.reshape(B, F).T)
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(owner, minlength=P))
+
+
 # ---------------------------------------------------------------------------------------------
 # strided tables / fused [embed | w | pad] rows
 # ---------------------------------------------------------------------------------------------

@@ -107,6 +107,133 @@ def test_oracle_backend_matches_bucketize_contract():
     assert torch.equal(local, ids[perm] - owner * 25)
 
 
+class OracleStepBackend:
+    """CPU stand-in for engine.HipStepBackend (TEST ONLY): the oracle plays the device kernels so that the 2-rank
+    exchange logic of ShardedDeepFMStep (unique-first splits, 1/P scaling, flat all-reduce) runs under gloo."""
+
+    class _Now:
+        def __init__(self, t):
+            self.v = t.tolist()
+
+        def get(self):
+            return self.v[0], self.v[1]
+
+    def __init__(self, step, field_dims, field_offsets):
+        self.step = step
+
+    def fork(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def join(self):
+        pass
+
+    def plan(self, cols, buf):
+        st = self.step
+        X = np.concatenate([c.numpy().reshape(-1, 1) for c in cols], 1)                 # [B,F]
+        uid, inv = np.unique(X, return_inverse=True)
+        owner = uid // st.rows_per_shard
+        return {"uid_local": torch.from_numpy(uid - owner * st.rows_per_shard),
+                "uidx": torch.from_numpy(inv.reshape(X.shape).T.copy()),                # [F,B]
+                "counts": torch.from_numpy(np.bincount(owner, minlength=st.P).astype(np.int64)),
+                "n_uniq": torch.tensor([len(uid)])}
+
+    counts_to_host = _Now
+    gather = staticmethod(OracleBackend.gather)
+
+    def rows_step(self, pl, rows_local, y):
+        from oracle import torch_ref as T
+        st = self.step
+        lay, B, F = st.layer, st.B, st.F
+        rows = rows_local.double().requires_grad_()
+        pr = {k: v.detach().double().requires_grad_() for k, v in lay.named_parameters()
+              if k not in ("embed.embeddings", "w.embeddings")}
+        p = {"embed": rows[:, :16], "w": rows[:, 16:17], "bias": pr["bias"],
+             "k1": [pr["MLP_layer1.kernel_0"], pr["MLP_layer1.kernel_1"]],
+             "b1": [pr["MLP_layer1.bias_0"], pr["MLP_layer1.bias_1"]],
+             "k2": [pr["MLP_layer2.kernel_0"]], "b2": [pr["MLP_layer2.bias_0"]]}
+        loss = T.keras_bce(y.double(), T.deepfm_forward(p, pl["uidx"].T.contiguous()))
+        loss.backward()
+        st.loss.copy_(loss.detach().float().reshape(1))
+        for k in st.g:
+            st.g[k].copy_(pr[k].grad.float().reshape(st.g[k].shape))
+        self._row_grad = rows.grad                       # already summed per unique id by autograd
+        return None, None
+
+    def local_grad(self, pl, vals, gz):
+        return self._row_grad[:, :16].float().contiguous(), self._row_grad[:, 16:17].float().contiguous()
+
+    def owner_reduce(self, their_ids, recv_counts, ge_theirs, gw_theirs, scale):
+        c = recv_counts.tolist()
+        o = 0
+        for k in c:                                      # contract of the merge: every list ascending and unique
+            part = their_ids[o:o + k].numpy()
+            assert np.all(part[1:] > part[:-1])
+            o += k
+        u, re_, nu = OracleBackend.dedup_sum(their_ids, ge_theirs, 0)
+        _, rw, _ = OracleBackend.dedup_sum(their_ids, gw_theirs, 0)
+        return u, re_ * scale, rw * scale, nu
+
+    def check_flags(self):
+        pass
+
+
+def _step_worker(rank, world, port, V, B, names, result):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from explicit_tf2_recommendation_amd import engine, data, layers
+        from oracle import torch_ref as T
+        layers.set_init_seed(3)
+        layer = layers.DeepFMRankingLayer(feature_names=names, feature_dims=V, embedding_dims=16)   # CPU parameters
+        with torch.no_grad():
+            layer.embed.embeddings.mul_(6.0)
+        batches = [data.SyntheticGenerator(names, V, dist="zipf", seed=50 + r).batch(B) for r in range(world)]
+        mine = {k: torch.from_numpy(v) for k, v in batches[rank].items()}
+        gen0 = data.SyntheticGenerator(names, V, seed=0)
+        step = engine.ShardedDeepFMStep(layer, B, gen0.dims, gen0.offsets, backend=OracleStepBackend)
+        nxt = {k: torch.from_numpy(v) for k, v in data.SyntheticGenerator(names, V, seed=90 + rank).batch(B).items()}
+        loss = step(mine, next_inputs=nxt).item()                  # announces a next batch: the pipelined branch
+        # oracle on the concatenated global batch with the full table
+        pr = {k: v.detach().double().requires_grad_() for k, v in layer.named_parameters()}
+        p = {"embed": pr["embed.embeddings"], "w": pr["w.embeddings"], "bias": pr["bias"],
+             "k1": [pr["MLP_layer1.kernel_0"], pr["MLP_layer1.kernel_1"]],
+             "b1": [pr["MLP_layer1.bias_0"], pr["MLP_layer1.bias_1"]],
+             "k2": [pr["MLP_layer2.kernel_0"]], "b2": [pr["MLP_layer2.bias_0"]]}
+        Xg = np.concatenate([L.index_assemble(b, names) for b in batches])
+        yg = np.concatenate([b["label"] for b in batches])
+        ref = T.keras_bce(torch.from_numpy(yg).double(), T.deepfm_forward(p, torch.from_numpy(Xg)))
+        ref.backward()
+        ok = [abs(loss - ref.item()) <= 1e-6]
+        for k, v in step.g.items():
+            want = pr[k].grad.reshape(v.shape)
+            ok.append(bool((v.double() - want).abs().max() <= 1e-6 + 1e-5 * want.abs().max()))
+        lo, hi = step.row_range
+        ids, rows_e, rows_w, nu = step.table_grad
+        nu = int(nu.item())
+        touched = np.unique(Xg)
+        touched = touched[(touched >= lo) & (touched < hi)]
+        ok.append(np.array_equal(ids.numpy()[:nu] + lo, touched))
+        we, ww = pr["embed.embeddings"].grad[touched], pr["w.embeddings"].grad[touched]
+        ok.append(bool((rows_e[:nu].double() - we).abs().max() <= 1e-6 + 1e-5 * we.abs().max()))
+        ok.append(bool((rows_w[:nu].double() - ww).abs().max() <= 1e-6 + 1e-5 * ww.abs().max()))
+        result[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_deepfm_step_two_ranks_gloo_matches_global_batch_oracle():
+    """world_size 2: per-rank batches, row-sharded table; loss, dense gradients and each owner's row gradients must
+    equal the oracle's on the concatenated batch of 2*B examples (mean loss over the global batch)."""
+    world, V, B = 2, 3001, 48
+    names = ["f%d" % i for i in range(6)]
+    mgr = mp.Manager()
+    result = mgr.dict()
+    mp.spawn(_step_worker, args=(world, _free_port(), V, B, names, result), nprocs=world, join=True)
+    assert all(all(v) for v in dict(result).values()) and len(result) == world, dict(result)
+
+
 # ------------------------------------------------------------------------------------------------
 # GPU
 # ------------------------------------------------------------------------------------------------
@@ -149,3 +276,116 @@ def test_sharded_embedding_world1_rccl():
         assert (got.double() - ref).abs().max().item() <= 1e-5
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_deepfm_step_world1_matches_fused_step():
+    """The sharded train step (bucketize -> RCCL all-to-all -> owner gather -> fused kernel on the returned rows ->
+    gradients back -> owner de-duplication) at world_size 1 against the single-GPU fused step on the same batch."""
+    from explicit_tf2_recommendation_amd import engine, data, layers
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        B, F, V = 1024, 26, 200000
+        names = ["f%d" % i for i in range(F)]
+        layers.set_init_seed(5)
+        layer = layers.DeepFMRankingLayer(feature_names=names, feature_dims=V, embedding_dims=16).cuda()
+        with torch.no_grad():
+            layer.embed.embeddings.mul_(2.0)
+        gen = data.SyntheticGenerator(names, V, dist="zipf", seed=5)
+        batch = data.to_device(gen.batch(B))
+        ref = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, use_graph=False)
+        sh = engine.ShardedDeepFMStep(layer, B, gen.dims, gen.offsets)
+        batch2 = data.to_device(gen.batch(B))
+        l_ref = ref(batch).item()
+        l_sh = sh(batch, next_inputs=batch2).item()
+        g_sh = {k: v.clone() for k, v in sh.g.items()}
+        tg = tuple(t.clone() for t in sh.table_grad)
+        # second step consumes the plan that was built beside the first one
+        assert abs(sh(batch2).item() - ref(batch2).item()) <= 1e-6
+        g_ref2 = ref.gradients()
+        for k, v in sh.g.items():
+            assert torch.equal(v, g_ref2[k]), k
+        sh.check_flags()
+        l_ref = ref(batch).item()
+        assert abs(l_ref - l_sh) <= 1e-6
+        g_ref = ref.gradients()
+        for k, v in g_sh.items():
+            assert torch.equal(v, g_ref[k]), k                       # same kernel on the same rows: bitwise
+        ids, rows_e, rows_w, nu = tg
+        nu = int(nu.item())
+        rid, re_, rnu = g_ref["embed.embeddings"]
+        assert nu == int(rnu.item()) and torch.equal(ids[:nu], rid[:nu])      # local id = global id at world 1
+        assert (rows_e[:nu] - re_[:nu]).abs().max().item() <= 1e-6
+        assert (rows_w[:nu] - g_ref["w.embeddings"][1][:nu]).abs().max().item() <= 1e-6
+    finally:
+        dist.destroy_process_group()
+
+
+def _gpu_step_worker(rank, world, port, V, B, F, result):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from explicit_tf2_recommendation_amd import engine, data, layers, sharded
+
+        class HostStagedComm(sharded.DistComm):
+            """gloo between two processes that share the ONE GPU of the test box (RCCL refuses two ranks on one
+            device): payloads hop through host memory, everything else -- every kernel -- is the product path."""
+
+            def exchange_counts(self, counts):
+                return super().exchange_counts(counts.cpu()).cuda()
+
+            def all_to_all(self, x, in_splits, out_splits):
+                return super().all_to_all(x.cpu(), in_splits, out_splits).cuda()
+
+            def all_reduce_sum(self, x):
+                x.copy_(super().all_reduce_sum(x.cpu()))
+                return x
+
+        torch.cuda.set_device(0)
+        names = ["f%d" % i for i in range(F)]
+        layers.set_init_seed(11)
+        layer = layers.DeepFMRankingLayer(feature_names=names, feature_dims=V, embedding_dims=16).cuda()
+        with torch.no_grad():
+            layer.embed.embeddings.mul_(2.0)
+        gens = [data.SyntheticGenerator(names, V, dist="zipf", seed=70 + r) for r in range(world)]
+        batches = [g.batch(B) for g in gens]
+        step = engine.ShardedDeepFMStep(layer, B, gens[0].dims, gens[0].offsets, comm=HostStagedComm())
+        warm = data.to_device(gens[rank].batch(B))
+        step(warm, next_inputs=data.to_device(batches[rank]))        # the measured step runs on a pipelined plan
+        loss = step(data.to_device(batches[rank])).item()
+        # single-GPU fused step on the concatenated global batch (same device, full table)
+        cat = {k: np.concatenate([b[k] for b in batches]) for k in batches[0]}
+        ref = engine.DeepFMFusedStep(layer, world * B, gens[0].dims, gens[0].offsets, use_graph=False)
+        l_ref = ref(data.to_device(cat)).item()
+        g_ref = ref.gradients()
+        ok = [abs(loss - l_ref) <= 2e-6]
+        for k, v in step.g.items():
+            ok.append(bool((v - g_ref[k]).abs().max() <= 1e-7 + 2e-5 * g_ref[k].abs().max()))
+        lo, hi = step.row_range
+        ids, rows_e, rows_w, nu = step.table_grad
+        nu = int(nu.item())
+        rid, re_, rnu = g_ref["embed.embeddings"]
+        rnu = int(rnu.item())
+        rid, re_, rw_ = rid[:rnu], re_[:rnu], g_ref["w.embeddings"][1][:rnu]
+        m = (rid >= lo) & (rid < hi)
+        ok.append(bool(nu == int(m.sum().item()) and torch.equal(ids[:nu] + lo, rid[m])))
+        ok.append(bool((rows_e[:nu] - re_[m]).abs().max() <= 1e-7 + 2e-5 * re_.abs().max()))
+        ok.append(bool((rows_w[:nu] - rw_[m]).abs().max() <= 1e-7 + 2e-5 * rw_.abs().max()))
+        ok.append(int(step.oob.item()) == 0)
+        result[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_deepfm_step_two_ranks_hip_kernels_match_single_gpu_global_batch():
+    """Two ranks (two processes on the one GPU, gloo through host memory) with the HIP kernels: loss, dense
+    gradients and the owners' row gradients against the single-GPU fused step on the concatenated batch."""
+    world, V, B, F = 2, 200001, 512, 26
+    mgr = mp.Manager()
+    result = mgr.dict()
+    mp.spawn(_gpu_step_worker, args=(world, _free_port(), V, B, F, result), nprocs=world, join=True)
+    assert len(result) == world and all(all(v) for v in dict(result).values()), dict(result)
