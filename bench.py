@@ -106,6 +106,10 @@ def cpu_baseline(args, names, seconds):
 
 def main():
     args = parse()
+    # RCCL prints its version banner on stdout: keep stdout for the ONE JSON line, send everything else to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -172,6 +176,26 @@ def main():
     loss = float(step.loss.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
+
+    replicas = None
+    if sharded_mode and not args.generic:
+        # reference point for the cost of the exchange: the same batches through the single-GPU fused step on a full
+        # table replica per rank (no collective at all), timed the same way.  NOT the reported value.
+        rstep = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, optimizer=None, use_graph=not args.no_graph)
+        for i in range(nw):
+            rstep(batches[i % n_batches], next_inputs=batches[(i + 1) % n_batches])
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            rstep(batches[i % n_batches], next_inputs=batches[(i + 1) % n_batches])
+        barrier()
+        rel = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([rel], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rel = float(t.item())
+        replicas = {"value": world * B * args.steps / rel, "unit": "examples/s", "ms_per_step": rel / args.steps * 1e3,
+                    "note": "independent full-table replicas, no exchange (upper bound; not the reported value)"}
 
     # ---- rooflines.  Average launch durations are measured live with HIP events around `reps` back-to-back launches
     # replayed from a hipGraph (events and replay share torch's current stream); `traffic` = HBM bytes per launch
@@ -288,10 +312,13 @@ def main():
                           "fused: fwd+bwd kernel, reduce, segment sums; de-duplication plan of batch k+1 (per-column "
                           "sort, second stream) overlaps step k"},
                "roofline": roofline, "roofline_gather": roofline_gather, "loss": loss}
+        if replicas is not None:
+            out["replicas_no_exchange"] = replicas
         out.update(extra)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, names, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 

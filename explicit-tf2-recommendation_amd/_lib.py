@@ -51,6 +51,7 @@ SIGNATURES = {
     "rec_colsort_workspace_bytes": (sz, [i64, i32]),
     "rec_colsort_plan_i64": (i32, [p, i32, i64, i64, p, i64, p, p, p, p, p, p, p]),
     "rec_colseg_sum_f32": (i32, [p, p, p, p, p, p, i64, i32, p, p, p, p, p]),
+    "rec_colseg_sum_packed_f32": (i32, [p, p, p, p, p, p, i64, i32, p, p, p, p]),
     "rec_din_prepare_f32": (i32, [p, p, i32, i32, p, p, p, p]),
     "rec_din_prepare_bwd_f32": (i32, [p, p, i32, i32, p, p]),
     "rec_din_attn_fwd_f32": (i32, [p, i64, i64, i32, i32, p, i64, i32, p, p, i32, i32, p, p, p, p, p, i64, i32, p, p, p,

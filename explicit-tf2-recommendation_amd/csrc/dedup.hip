@@ -173,9 +173,30 @@ __global__ __launch_bounds__(256) void segsum_chunk_kernel(const float* __restri
     span = nspan < step ? nspan : step;
     lo = nlo;
   }
-  for (int u = lo; u < (int)n && seg_start[u] < c1; ++u) {
-    int s0 = seg_start[u], s1 = seg_start[u + 1];
-    if (s1 - s0 <= LONG) continue;
+  // Only runs longer than LONG (>= CH) matter here, and at most two of them touch a chunk: the run that covers c0 and
+  // the last run that starts inside the chunk.  All runs that start before c1 (<= 256 from `lo` on) are tested at
+  // once, one per thread, instead of being walked one after the other.
+  __shared__ int long_s0[2], long_s1[2];
+  if (tid < 2) long_s0[tid] = -1;
+  __syncthreads();
+  {
+    int u = lo + tid;
+    if (u < (int)n) {
+      int s0 = seg_start[u];
+      if (s0 < c1) {
+        int s1 = seg_start[u + 1];
+        if (s1 - s0 > LONG) {
+          int which = s0 <= c0 ? 0 : 1;
+          long_s0[which] = s0;
+          long_s1[which] = s1;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int which = 0; which < 2; ++which) {
+    int s0 = long_s0[which], s1 = long_s1[which];
+    if (s0 < 0) continue;                                   // workgroup-uniform
     int a = s0 > c0 ? s0 : c0, b = s1 < c1 ? s1 : c1;
     float acc = 0.f;
     if (d < E)
@@ -187,7 +208,6 @@ __global__ __launch_bounds__(256) void segsum_chunk_kernel(const float* __restri
       if (slot < k) red[tid] += red[tid + k * GE];
       __syncthreads();
     }
-    int which = s0 <= c0 ? 0 : 1;
     if (slot == 0 && d < E) part[((int64_t)blockIdx.x * 2 + which) * E + d] = red[d];
     __syncthreads();
   }

@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256) void colseg_sum_kernel(const float4* __restric
                                                          const int32_t* __restrict__ col_seg, const int32_t* __restrict__ col_nu,
                                                          int64_t B, int F, int64_t* __restrict__ uniq_ids,
                                                          float4* __restrict__ g_embed, float* __restrict__ g_w,
-                                                         int64_t* __restrict__ n_uniq) {
+                                                         int64_t* __restrict__ n_uniq, int packed) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int c = tid & 3;                       // float4 chunk of the 16-float row
   const int64_t grp = ((int64_t)blockIdx.x * 256 + tid) >> 2;      // (f, u_local) = (grp / B, grp % B)
@@ -721,11 +721,14 @@ __global__ __launch_bounds__(256) void colseg_sum_kernel(const float4* __restric
     acc = make_float4(0.f, 0.f, 0.f, 0.f);
     accw = 0.f;
   }
-  g_embed[dst * 4 + c] = acc;
-  if (c == 0) {
-    g_w[dst] = accw;
-    uniq_ids[dst] = idv;
+  if (packed) {                                  // rows of 20 floats: [embed 16 | w | 0 0 0] (one exchange buffer)
+    g_embed[dst * 5 + c] = acc;
+    if (c == 0) g_embed[dst * 5 + 4] = make_float4(accw, 0.f, 0.f, 0.f);
+  } else {
+    g_embed[dst * 4 + c] = acc;
+    if (c == 0) g_w[dst] = accw;
   }
+  if (c == 0) uniq_ids[dst] = idv;
   if (grp == 0 && c == 0) *n_uniq = total;
 }
 
@@ -833,7 +836,22 @@ extern "C" int rec_colseg_sum_f32(const float* vals, const float* gz, const int3
   int64_t groups = B * F;
   hipLaunchKernelGGL(colseg_sum_kernel, dim3((unsigned)ceil_div64(groups * 4, 256)), dim3(256), 0, as_stream(stream),
                      (const float4*)vals, gz, perm, col_uid, col_seg, col_nu, B, F, uniq_ids, (float4*)g_embed_rows,
-                     g_w_rows, n_uniq);
+                     g_w_rows, n_uniq, 0);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_colseg_sum_packed_f32(const float* vals, const float* gz, const int32_t* perm, const int64_t* col_uid,
+                                         const int32_t* col_seg, const int32_t* col_nu, int64_t B, int F,
+                                         int64_t* uniq_ids, float* g_rows, int64_t* n_uniq, void* stream) {
+  if (!vals || !gz || !perm || !col_uid || !col_seg || !col_nu || !uniq_ids || !g_rows || !n_uniq || B <= 0 || F <= 0)
+    return REC_E_ARG;
+  if ((reinterpret_cast<uintptr_t>(vals) & 15) != 0 || (reinterpret_cast<uintptr_t>(g_rows) & 15) != 0)
+    return REC_E_UNSUPPORTED;
+  int64_t groups = B * F;
+  hipLaunchKernelGGL(colseg_sum_kernel, dim3((unsigned)ceil_div64(groups * 4, 256)), dim3(256), 0, as_stream(stream),
+                     (const float4*)vals, gz, perm, col_uid, col_seg, col_nu, B, F, uniq_ids, (float4*)g_rows,
+                     (float*)nullptr, n_uniq, 1);
   REC_LAUNCH_CHECK();
   return REC_OK;
 }

@@ -480,8 +480,7 @@ class HipStepBackend:
         self.gz = torch.empty(B, **f32)
         self.vals = torch.empty((n, 16), **f32)
         self.uniq_ids = torch.empty(n, **i64)
-        self.ge = torch.empty((n, 16), **f32)
-        self.gw = torch.empty((n, 1), **f32)
+        self.grows = torch.empty((n, 20), **f32)          # [embed 16 | w | pad 3] per unique id: one exchange buffer
         self.n_uniq = torch.zeros(1, **i64)
         self.ws = torch.empty(lib.rec_deepfm_fused_workspace_bytes(B, F), dtype=torch.uint8, device=dev)
         self.side = torch.cuda.Stream(device=dev)
@@ -530,22 +529,23 @@ class HipStepBackend:
         return self.vals, self.gz
 
     def local_grad(self, pl, vals, gz):
-        """This batch's gradient per unique id (embed [n,16], w [n,1]; first n_uniq rows, ascending id = send order)."""
+        """This batch's gradient per unique id as rows [embed 16 | w | 0 0 0] ([n,20]; first n_uniq rows, ascending
+        id = send order)."""
         st_ = self.step
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(lib.rec_colseg_sum_f32(_p(vals), _p(gz), _p(pl["perm"]), _p(pl["col_uid"]), _p(pl["col_seg"]),
-                                     _p(pl["col_nu"]), st_.B, st_.F, _p(self.uniq_ids), _p(self.ge), _p(self.gw),
-                                     _p(self.n_uniq), st), "rec_colseg_sum_f32")
-        return self.ge, self.gw
+        check(lib.rec_colseg_sum_packed_f32(_p(vals), _p(gz), _p(pl["perm"]), _p(pl["col_uid"]), _p(pl["col_seg"]),
+                                            _p(pl["col_nu"]), st_.B, st_.F, _p(self.uniq_ids), _p(self.grows),
+                                            _p(self.n_uniq), st), "rec_colseg_sum_packed_f32")
+        return self.grows
 
-    def owner_reduce(self, their_ids, recv_counts, ge_theirs, gw_theirs, scale):
-        """Union of the P ascending id lists that arrived + row sums in list order, times ``scale``."""
+    def owner_reduce(self, their_ids, recv_counts, rows_theirs, scale):
+        """Union of the P ascending id lists that arrived + row sums in list order, times ``scale``.
+        Returns (uniq local ids, embed rows [.,16], w rows [.,1] -- views of one [.,20] buffer --, n_uniq)."""
         plan = ops.DedupPlan(their_ids, self.step.rows_per_shard, list_counts=recv_counts)
-        ge, gw = plan.segment_sum(ge_theirs, 16), plan.segment_sum(gw_theirs, 1)
+        rows = plan.segment_sum(rows_theirs, 20)
         if scale != 1.0:
-            ops.axpby(scale, ge, 0.0, ge)
-            ops.axpby(scale, gw, 0.0, gw)
-        return plan.uniq_ids, ge, gw, plan.n_uniq
+            ops.axpby(scale, rows, 0.0, rows)
+        return plan.uniq_ids, rows[:, :16], rows[:, 16:17], plan.n_uniq
 
     def check_flags(self):
         if int(self.bad_ids.item()) != 0:
@@ -565,7 +565,8 @@ class ShardedDeepFMStep:
         C2  all-to-all of the rows back -> a local [n_uniq, 32] table in id order: no permutation anywhere
         --  the fused forward+backward kernel on those rows (it gathers by the compact index of each lookup),
             then the per-unique-id segment sums of the row gradients (embed 16 + w 1), in send order
-        C3  all-to-all of the summed row gradients to the owners, who merge the P ascending lists (rank merge)
+        C3  all-to-all of the summed row gradients (one [.,20] buffer) to the owners, who merge the P ascending
+            lists (rank merge)
         C4  one flat all-reduce (SUM) of the dense gradients and the loss, divided by P
 
     The loss is the mean over the GLOBAL batch of P*B examples (2.FM/ModelManager.py:171-177 on the concatenated
@@ -663,11 +664,10 @@ class ShardedDeepFMStep:
                 self._finish_plan(nxt)                       # C0 of the next batch rides behind C2 on the RCCL stream
             self._next = (tuple(c.data_ptr() for c in next_cols), 1 - buf, nxt)
         vals, gz = be.rows_step(pl, rows_local, y)
-        ge, gw = be.local_grad(pl, vals, gz)
-        ge_theirs = comm.all_to_all(ge[:nu], send, recv)                       # C3
-        gw_theirs = comm.all_to_all(gw[:nu], send, recv)
+        grows = be.local_grad(pl, vals, gz)
+        rows_theirs = comm.all_to_all(grows[:nu], send, recv)                  # C3
         if their_ids.numel():
-            self.table_grad = be.owner_reduce(their_ids, pl["recv"], ge_theirs, gw_theirs, 1.0 / self.P)
+            self.table_grad = be.owner_reduce(their_ids, pl["recv"], rows_theirs, 1.0 / self.P)
         else:
             self.table_grad = None
         # C4: dense gradients and the loss, one flat all-reduce (mean over ranks = the global-batch gradient)

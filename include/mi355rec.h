@@ -222,6 +222,12 @@ int rec_colseg_sum_f32(const float* vals, const float* gz, const int32_t* perm, 
                        const int32_t* col_seg, const int32_t* col_nu, int64_t B, int F, int64_t* uniq_ids,
                        float* g_embed_rows, float* g_w_rows, int64_t* n_uniq, void* stream);
 
+/* Same sums written as rows of 20 floats [embed 16 | w | 0 0 0] (g_rows [B*F,20]): ONE buffer to send to the shard
+ * owners in the row-sharded step. */
+int rec_colseg_sum_packed_f32(const float* vals, const float* gz, const int32_t* perm, const int64_t* col_uid,
+                              const int32_t* col_seg, const int32_t* col_nu, int64_t B, int F, int64_t* uniq_ids,
+                              float* g_rows, int64_t* n_uniq, void* stream);
+
 /* ---- K8/K9  DIN ActivationUnit + masked sum pooling (5.DIN/CustomLayers.py:163-180, 256-282), factorised:
  *   pre[b,t,:] = c_b + k_t . Eff_b,  Eff_b = (W_k - W_d) + M_b,  M_b[i,o] = sum_j q_j W_o[i,j,o],
  *   c_b = q (W_q + W_d) + b1;  score = act(pre) . w2 + b2;  pooled[b,:] = sum_t mask[b,t] * score[b,t] * k_t.

@@ -161,18 +161,18 @@ class OracleStepBackend:
         return None, None
 
     def local_grad(self, pl, vals, gz):
-        return self._row_grad[:, :16].float().contiguous(), self._row_grad[:, 16:17].float().contiguous()
+        return self._row_grad[:, :20].float().contiguous()         # [embed 16 | w | pad]: autograd leaves pad = 0
 
-    def owner_reduce(self, their_ids, recv_counts, ge_theirs, gw_theirs, scale):
+    def owner_reduce(self, their_ids, recv_counts, rows_theirs, scale):
         c = recv_counts.tolist()
         o = 0
         for k in c:                                      # contract of the merge: every list ascending and unique
             part = their_ids[o:o + k].numpy()
             assert np.all(part[1:] > part[:-1])
             o += k
-        u, re_, nu = OracleBackend.dedup_sum(their_ids, ge_theirs, 0)
-        _, rw, _ = OracleBackend.dedup_sum(their_ids, gw_theirs, 0)
-        return u, re_ * scale, rw * scale, nu
+        u, rows, nu = OracleBackend.dedup_sum(their_ids, rows_theirs, 0)
+        rows = rows * scale
+        return u, rows[:, :16], rows[:, 16:17], nu
 
     def check_flags(self):
         pass
