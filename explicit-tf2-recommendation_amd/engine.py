@@ -436,13 +436,17 @@ class DeepFMFusedStep:
 
 
 class _HostCounts:
-    """[2,P] split sizes on their way to the host: pinned copy + event, read when the step that needs them starts."""
+    """[2,P] split sizes on their way to the host: pinned buffer + event (both reused), read when the step that needs
+    them starts."""
 
-    def __init__(self, dev_counts):
-        self.host = torch.empty(tuple(dev_counts.shape), dtype=dev_counts.dtype, pin_memory=True)
-        self.host.copy_(dev_counts, non_blocking=True)
+    def __init__(self, P):
+        self.host = torch.empty((2, P), dtype=torch.int64, pin_memory=True)
         self.event = torch.cuda.Event()
+
+    def send(self, dev_counts):
+        self.host.copy_(dev_counts, non_blocking=True)
         self.event.record()
+        return self
 
     def get(self):
         self.event.synchronize()
@@ -453,7 +457,11 @@ class _HostCounts:
 class HipStepBackend:
     """Device-side pieces of ShardedDeepFMStep, all HIP kernels on preallocated buffers.  The CPU gloo test
     (tests/test_sharded.py) injects an oracle-backed stand-in with the same methods to exercise the exchange logic
-    without a GPU; the product never does."""
+    without a GPU; the product never does.
+
+    The host issues ~15 C-ABI calls and 4 collectives per step and must stay ahead of the GPU, so nothing here looks up
+    torch's current stream or builds pointer arrays more than once: `begin()` caches the stream handles of a step,
+    the per-plan pointer arrays are built at construction, the owner-side buffers only ever grow."""
 
     def __init__(self, step, field_dims, field_offsets):
         self.step = step
@@ -473,8 +481,12 @@ class HipStepBackend:
         self.plans = [dict(perm=torch.empty((F, B), **i32), col_uid=torch.empty((F, B), **i64),
                            col_seg=torch.empty((F, B + 1), **i32), col_nu=torch.zeros(F, **i32),
                            uid_local=torch.empty(n, **i64), uidx=torch.empty((F, B), **i64),
-                           counts=torch.zeros(P, **i64), recv=torch.zeros(P, **i64),
+                           counts2=torch.zeros((2, P), **i64),      # row 0: unique ids per owner, row 1: received
                            n_uniq=torch.zeros(1, **i64)) for _ in range(2)]
+        for pl in self.plans:
+            pl["counts"], pl["recv"] = pl["counts2"][0], pl["counts2"][1]
+            pl["uidx_arr"] = (C.c_void_p * F)(*[pl["uidx"][f].data_ptr() for f in range(F)])
+        self.host_counts = [_HostCounts(P) for _ in range(2)]
         self.sort_ws = [torch.empty(lib.rec_colsort_workspace_bytes(B, F), dtype=torch.uint8, device=dev)
                         for _ in range(2)]
         self.gz = torch.empty(B, **f32)
@@ -484,23 +496,42 @@ class HipStepBackend:
         self.n_uniq = torch.zeros(1, **i64)
         self.ws = torch.empty(lib.rec_deepfm_fused_workspace_bytes(B, F), dtype=torch.uint8, device=dev)
         self.side = torch.cuda.Stream(device=dev)
+        self.side_ctx = torch.cuda.stream(self.side)
+        self.side_st = C.c_void_p(self.side.cuda_stream)
+        self.main, self.st = None, None
+        self._cap = 0                                     # owner-side capacity (ids received), grow-only
+        self._arr_cache = {}
 
     # -- streams: the plan of the next batch depends on ids only and is built beside the current step
+    def begin(self):
+        self.main = torch.cuda.current_stream()
+        self.st = C.c_void_p(self.main.cuda_stream)
+
     def fork(self):
-        self.side.wait_stream(torch.cuda.current_stream())
-        return torch.cuda.stream(self.side)
+        self.side.wait_stream(self.main)
+
+    def side_context(self):
+        return self.side_ctx
 
     def join(self):
-        torch.cuda.current_stream().wait_stream(self.side)
+        self.main.wait_stream(self.side)
 
-    def plan(self, cols, buf):
+    def _col_arr(self, cols):
+        key = tuple(c.data_ptr() for c in cols)
+        arr = self._arr_cache.get(key)
+        if arr is None:
+            if len(self._arr_cache) > 64:
+                self._arr_cache.clear()
+            arr = self._arr_cache[key] = (C.c_void_p * len(cols))(*key)
+        return arr
+
+    def plan(self, cols, buf, on_side=False):
         """Per-column sort + unique (rec_colsort_plan_i64), then the exchange map (rec_colsort_shard_map_i64)."""
         st_ = self.step
         B, F = st_.B, st_.F
         pl = self.plans[buf]
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        arr = (C.c_void_p * F)(*[c.data_ptr() for c in cols])
-        check(lib.rec_colsort_plan_i64(arr, F, B, st_.V, _p(self.col_lo), self.max_key, _p(pl["perm"]),
+        st = self.side_st if on_side else self.st
+        check(lib.rec_colsort_plan_i64(self._col_arr(cols), F, B, st_.V, _p(self.col_lo), self.max_key, _p(pl["perm"]),
                                        _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.bad_ids),
                                        _p(self.sort_ws[buf]), st), "rec_colsort_plan_i64")
         check(lib.rec_colsort_shard_map_i64(_p(pl["perm"]), _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), B, F,
@@ -509,43 +540,70 @@ class HipStepBackend:
               "rec_colsort_shard_map_i64")
         return pl
 
-    counts_to_host = staticmethod(_HostCounts)
-    gather = staticmethod(ops.emb_gather)
+    def counts_to_host(self, pl, buf):
+        return self.host_counts[buf].send(pl["counts2"])
+
+    def gather(self, table, ids):
+        m = ids.numel()
+        out = torch.empty((m, 32), dtype=torch.float32, device=table.device)
+        check(lib.rec_emb_gather_f32(_p(table), table.shape[0], 32, 32, _p(ids), m, _p(out), _p(self.step.oob), self.st),
+              "rec_emb_gather_f32")
+        return out
 
     def rows_step(self, pl, rows_local, y):
         """The fused forward+backward kernel on the exchanged rows: the local [n_uniq,32] buffer is the "table" and
         the ids are the compact indices uidx.  Fills step.g / step.loss; returns (vals [n,16], gz [B])."""
         st_ = self.step
-        L, B, F, g = st_.layer, st_.B, st_.F, st_.g
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        arr = (C.c_void_p * F)(*[pl["uidx"][f].data_ptr() for f in range(F)])
+        L, g = st_.layer, st_.g
         check(lib.rec_deepfm_fused_fwd_bwd_f32(
-            _p(rows_local), 32, rows_local.shape[0], arr, F, B, _p(L.bias), _p(L.MLP_layer1.kernel_0),
-            _p(L.MLP_layer1.bias_0), _p(L.MLP_layer1.kernel_1), _p(L.MLP_layer1.bias_1), _p(L.MLP_layer2.kernel_0),
-            _p(L.MLP_layer2.bias_0), _p(y), _p(self.gz), _p(self.vals), None, _p(g["MLP_layer1.kernel_0"]),
-            _p(g["MLP_layer1.bias_0"]), _p(g["MLP_layer1.kernel_1"]), _p(g["MLP_layer1.bias_1"]),
-            _p(g["MLP_layer2.kernel_0"]), _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(st_.loss), _p(st_.oob),
-            _p(self.ws), st), "rec_deepfm_fused_fwd_bwd_f32")
+            _p(rows_local), 32, rows_local.shape[0], pl["uidx_arr"], st_.F, st_.B, _p(L.bias),
+            _p(L.MLP_layer1.kernel_0), _p(L.MLP_layer1.bias_0), _p(L.MLP_layer1.kernel_1), _p(L.MLP_layer1.bias_1),
+            _p(L.MLP_layer2.kernel_0), _p(L.MLP_layer2.bias_0), _p(y), _p(self.gz), _p(self.vals), None,
+            _p(g["MLP_layer1.kernel_0"]), _p(g["MLP_layer1.bias_0"]), _p(g["MLP_layer1.kernel_1"]),
+            _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]), _p(g["MLP_layer2.bias_0"]), _p(g["bias"]),
+            _p(st_.loss), _p(st_.oob), _p(self.ws), self.st), "rec_deepfm_fused_fwd_bwd_f32")
         return self.vals, self.gz
 
     def local_grad(self, pl, vals, gz):
         """This batch's gradient per unique id as rows [embed 16 | w | 0 0 0] ([n,20]; first n_uniq rows, ascending
         id = send order)."""
         st_ = self.step
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(lib.rec_colseg_sum_packed_f32(_p(vals), _p(gz), _p(pl["perm"]), _p(pl["col_uid"]), _p(pl["col_seg"]),
                                             _p(pl["col_nu"]), st_.B, st_.F, _p(self.uniq_ids), _p(self.grows),
-                                            _p(self.n_uniq), st), "rec_colseg_sum_packed_f32")
+                                            _p(self.n_uniq), self.st), "rec_colseg_sum_packed_f32")
         return self.grows
+
+    def _owner_buffers(self, m):
+        if m > self._cap:
+            cap = int(m * 1.25) + 1024
+            dev = self.step.dev
+            self.o_uniq = torch.empty(cap, dtype=torch.int64, device=dev)
+            self.o_seg = torch.empty(cap + 1, dtype=torch.int32, device=dev)
+            self.o_perm = torch.empty(cap, dtype=torch.int32, device=dev)
+            self.o_nu = torch.zeros(1, dtype=torch.int64, device=dev)
+            self.o_rows = torch.empty((cap, 20), dtype=torch.float32, device=dev)
+            self.o_ws_bytes = lib.rec_dedup_workspace_bytes(cap)
+            self.o_ws = torch.empty(self.o_ws_bytes, dtype=torch.uint8, device=dev)
+            self.o_sws = torch.empty(lib.rec_segment_sum_workspace_bytes(cap, 20), dtype=torch.uint8, device=dev)
+            self._cap = cap
 
     def owner_reduce(self, their_ids, recv_counts, rows_theirs, scale):
         """Union of the P ascending id lists that arrived + row sums in list order, times ``scale``.
-        Returns (uniq local ids, embed rows [.,16], w rows [.,1] -- views of one [.,20] buffer --, n_uniq)."""
-        plan = ops.DedupPlan(their_ids, self.step.rows_per_shard, list_counts=recv_counts)
-        rows = plan.segment_sum(rows_theirs, 20)
+        Returns (uniq local ids, embed rows [.,16], w rows [.,1] -- views of one [.,20] buffer that the next step
+        overwrites --, n_uniq)."""
+        m = their_ids.numel()
+        self._owner_buffers(m)
+        st = self.st
+        check(lib.rec_dedup_plan_sorted_lists_i64(_p(their_ids), m, _p(recv_counts), recv_counts.numel(),
+                                                  self.step.rows_per_shard, _p(self.o_uniq), _p(self.o_seg),
+                                                  _p(self.o_perm), _p(self.o_nu), _p(self.o_ws), self.o_ws_bytes, st),
+              "rec_dedup_plan_sorted_lists_i64")
+        check(lib.rec_segment_sum_f32(_p(rows_theirs), 20, _p(self.o_perm), _p(self.o_seg), m, 1, _p(self.o_rows),
+                                      _p(self.o_sws), st), "rec_segment_sum_f32")
+        rows = self.o_rows[:m]
         if scale != 1.0:
-            ops.axpby(scale, rows, 0.0, rows)
-        return plan.uniq_ids, rows[:, :16], rows[:, 16:17], plan.n_uniq
+            check(lib.rec_axpby_f32(scale, _p(rows), 0.0, _p(rows), rows.numel(), st), "rec_axpby_f32")
+        return self.o_uniq[:m], rows[:, :16], rows[:, 16:17], self.o_nu
 
     def check_flags(self):
         if int(self.bad_ids.item()) != 0:
@@ -559,7 +617,8 @@ class ShardedDeepFMStep:
 
         plan (ids only; built for batch k+1 on a second stream while batch k is differentiated)
             per-column sort + unique  ->  the batch's unique ids, ascending = already grouped by owner
-            C0  all-to-all of the per-owner unique-id counts; both count vectors travel to the host asynchronously
+            C0  all-to-all of the per-owner unique-id counts on its OWN communicator (own RCCL stream, so it does not
+                queue behind the payload collectives); both count vectors travel to the host asynchronously
         C1  all-to-all of the unique local ids                              (RCCL; "nccl" backend on ROCm)
         --  owner-side gather of the 128-byte fused rows                    (HIP, ids ascending)
         C2  all-to-all of the rows back -> a local [n_uniq, 32] table in id order: no permutation anywhere
@@ -578,7 +637,7 @@ class ShardedDeepFMStep:
 
     def __init__(self, layer, batch_size, field_dims, field_offsets, group=None, backend=None, comm=None):
         from . import sharded
-        self.comm = comm if comm is not None else sharded.DistComm(group)
+        self.comm = comm if comm is not None else sharded.DistComm(group, separate_count_channel=True)
         self.P, self.rank = self.comm.world, self.comm.rank
         self.layer = layer
         self.B = B = int(batch_size)
@@ -616,28 +675,35 @@ class ShardedDeepFMStep:
         }
         self.be = (backend or HipStepBackend)(self, field_dims, field_offsets)
         self._next = None               # (key, buffer, plan) announced by the previous call
+        self._cols_cache = {}
         self.table_grad = None          # (local uniq ids, embed rows [.,16], w rows [.,1], n_uniq) after a step
 
     def _cols(self, inputs):
+        hit = self._cols_cache.get(id(inputs))
+        if hit is not None and hit[0] is inputs:
+            return hit[1]
         cols = []
         for name in self.layer.feature_names:
             c = inputs[name]
             if c.dtype != torch.int64 or c.numel() != self.B or not c.is_contiguous():
                 raise ValueError("feature %r must be a contiguous int64 tensor with %d ids" % (name, self.B))
             cols.append(c)
+        if len(self._cols_cache) >= 16:
+            self._cols_cache.clear()
+        self._cols_cache[id(inputs)] = (inputs, cols)        # validated once per resident batch dict
         return cols
 
-    def _finish_plan(self, pl):
+    def _finish_plan(self, pl, buf):
         """C0 + the asynchronous hand-over of both split-size vectors to the host."""
-        recv = self.comm.exchange_counts(pl["counts"])
         if pl.get("recv") is not None:
-            pl["recv"].copy_(recv)                           # preallocated: outlives the stream it was produced on
+            self.comm.exchange_counts(pl["counts"], out=pl["recv"])   # preallocated: outlives the stream it is made on
         else:
-            pl["recv"] = recv
-        pl["host"] = self.be.counts_to_host(torch.stack([pl["counts"], recv]))
+            pl["recv"] = self.comm.exchange_counts(pl["counts"])
+        pl["host"] = self.be.counts_to_host(pl, buf)
 
     def __call__(self, inputs, label_name="label", next_inputs=None):
         be, comm = self.be, self.comm
+        be.begin()
         cols = self._cols(inputs)
         y = inputs[label_name]
         key = tuple(c.data_ptr() for c in cols)
@@ -647,22 +713,20 @@ class ShardedDeepFMStep:
         else:
             buf = 0
             pl = be.plan(cols, buf)
-            self._finish_plan(pl)
+            self._finish_plan(pl, buf)
         self._next = None
-        nxt = None
         if next_inputs is not None:
             next_cols = self._cols(next_inputs)
-            with be.fork():
-                nxt = be.plan(next_cols, 1 - buf)            # kernels only; its count exchange is issued below
-        send, recv = pl["host"].get()                        # split sizes (already on the host when pipelined)
+            be.fork()
+            nxt = be.plan(next_cols, 1 - buf, on_side=True)
+            with be.side_context():
+                self._finish_plan(nxt, 1 - buf)              # C0 of the next batch: own communicator, second stream
+            self._next = (tuple(c.data_ptr() for c in next_cols), 1 - buf, nxt)
+        send, recv = pl["host"].get()                        # split sizes (on the host a step early when pipelined)
         nu = sum(send)
         their_ids = comm.all_to_all(pl["uid_local"][:nu], send, recv)          # C1
         rows_out = be.gather(self.table_shard, their_ids)                      # owner-side gather of 128-B rows
         rows_local = comm.all_to_all(rows_out, recv, send)                     # C2: [n_uniq, 32] in ascending id order
-        if nxt is not None:
-            with be.fork():
-                self._finish_plan(nxt)                       # C0 of the next batch rides behind C2 on the RCCL stream
-            self._next = (tuple(c.data_ptr() for c in next_cols), 1 - buf, nxt)
         vals, gz = be.rows_step(pl, rows_local, y)
         grows = be.local_grad(pl, vals, gz)
         rows_theirs = comm.all_to_all(grows[:nu], send, recv)                  # C3

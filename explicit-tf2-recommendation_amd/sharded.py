@@ -45,16 +45,25 @@ class HipBackend:
 
 
 class DistComm:
-    """all-to-all over a torch.distributed process group (RCCL on the GPUs, gloo in the CPU tests)."""
+    """all-to-all over a torch.distributed process group (RCCL on the GPUs, gloo in the CPU tests).
 
-    def __init__(self, group=None):
+    ``separate_count_channel=True`` creates a second communicator over the same ranks for the tiny split-size exchange
+    (C0): it then has its own RCCL stream and does not queue behind the payload collectives of the step in flight,
+    which is what lets a pipelined step learn the next batch's split sizes a whole step early."""
+
+    def __init__(self, group=None, separate_count_channel=False):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.count_group = group
+        if separate_count_channel:
+            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(self.world))
+            self.count_group = dist.new_group(ranks=ranks)           # collective: every rank constructs its DistComm
 
-    def exchange_counts(self, counts):
-        out = torch.empty_like(counts)
-        dist.all_to_all_single(out, counts, group=self.group)
+    def exchange_counts(self, counts, out=None):
+        if out is None:
+            out = torch.empty_like(counts)
+        dist.all_to_all_single(out, counts, group=self.count_group)
         return out
 
     def all_to_all(self, x, in_splits, out_splits):

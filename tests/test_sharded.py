@@ -112,23 +112,29 @@ class OracleStepBackend:
     exchange logic of ShardedDeepFMStep (unique-first splits, 1/P scaling, flat all-reduce) runs under gloo."""
 
     class _Now:
-        def __init__(self, t):
-            self.v = t.tolist()
+        def __init__(self, send, recv):
+            self.v = (send.tolist(), recv.tolist())
 
         def get(self):
-            return self.v[0], self.v[1]
+            return self.v
 
     def __init__(self, step, field_dims, field_offsets):
         self.step = step
 
+    def begin(self):
+        pass
+
     def fork(self):
+        pass
+
+    def side_context(self):
         import contextlib
         return contextlib.nullcontext()
 
     def join(self):
         pass
 
-    def plan(self, cols, buf):
+    def plan(self, cols, buf, on_side=False):
         st = self.step
         X = np.concatenate([c.numpy().reshape(-1, 1) for c in cols], 1)                 # [B,F]
         uid, inv = np.unique(X, return_inverse=True)
@@ -138,8 +144,11 @@ class OracleStepBackend:
                 "counts": torch.from_numpy(np.bincount(owner, minlength=st.P).astype(np.int64)),
                 "n_uniq": torch.tensor([len(uid)])}
 
-    counts_to_host = _Now
-    gather = staticmethod(OracleBackend.gather)
+    def counts_to_host(self, pl, buf):
+        return self._Now(pl["counts"], pl["recv"])
+
+    def gather(self, table, ids):
+        return OracleBackend.gather(table, ids)
 
     def rows_step(self, pl, rows_local, y):
         from oracle import torch_ref as T
@@ -334,8 +343,9 @@ def _gpu_step_worker(rank, world, port, V, B, F, result):
             """gloo between two processes that share the ONE GPU of the test box (RCCL refuses two ranks on one
             device): payloads hop through host memory, everything else -- every kernel -- is the product path."""
 
-            def exchange_counts(self, counts):
-                return super().exchange_counts(counts.cpu()).cuda()
+            def exchange_counts(self, counts, out=None):
+                r = super().exchange_counts(counts.cpu()).cuda()
+                return r if out is None else out.copy_(r)
 
             def all_to_all(self, x, in_splits, out_splits):
                 return super().all_to_all(x.cpu(), in_splits, out_splits).cuda()
