@@ -675,22 +675,15 @@ class ShardedDeepFMStep:
         }
         self.be = (backend or HipStepBackend)(self, field_dims, field_offsets)
         self._next = None               # (key, buffer, plan) announced by the previous call
-        self._cols_cache = {}
         self.table_grad = None          # (local uniq ids, embed rows [.,16], w rows [.,1], n_uniq) after a step
 
     def _cols(self, inputs):
-        hit = self._cols_cache.get(id(inputs))
-        if hit is not None and hit[0] is inputs:
-            return hit[1]
         cols = []
         for name in self.layer.feature_names:
             c = inputs[name]
             if c.dtype != torch.int64 or c.numel() != self.B or not c.is_contiguous():
                 raise ValueError("feature %r must be a contiguous int64 tensor with %d ids" % (name, self.B))
             cols.append(c)
-        if len(self._cols_cache) >= 16:
-            self._cols_cache.clear()
-        self._cols_cache[id(inputs)] = (inputs, cols)        # validated once per resident batch dict
         return cols
 
     def _finish_plan(self, pl, buf):
