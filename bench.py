@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=CFG["batch"])
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly (no hipGraph replay)")
+    ap.add_argument("--step-graphs", action="store_true", help="one hipGraph per step instead of one per 4-step cycle")
     ap.add_argument("--generic", action="store_true", help="use the generic ~35-kernel step instead of the fused one")
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1: independent full-table replicas instead of the row-sharded table + RCCL all-to-all")
@@ -153,14 +154,29 @@ def main():
         else:   # the next batch is announced: its de-duplication plan is built while this one is differentiated
             step(batches[i % n_batches], next_inputs=batches[(i + 1) % n_batches])
 
+    # launch-bound inner loop: the n_batches resident batches are replayed as ONE captured hipGraph of n_batches steps
+    # (one graph launch costs ~20 us of idle GPU); --step-graphs keeps one graph per step
+    cycle = (not sharded_mode) and (not args.generic) and (not args.no_graph) and (not args.step_graphs)
+
+    def run_steps(n):
+        i = 0
+        if cycle:
+            while n - i >= n_batches:
+                step.many(batches, then=batches[0])
+                i += n_batches
+        while i < n:
+            run(i)
+            i += 1
+
     nw = max(args.warmup, 2 * n_batches)                 # warm-up also captures the hipGraphs of the resident batches
     nw += (-nw) % n_batches                              # ... and ends where the timed loop starts (batch 0)
-    for i in range(nw):
-        run(i)
+    run_steps(nw)
+    if cycle and args.steps % n_batches:
+        for i in range(n_batches):                       # the single-step graphs of a ragged tail
+            run(i)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        run(i)
+    run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -304,7 +320,8 @@ def main():
                                           "all-reduce of dense gradients") if sharded_mode else
                           ("1 process per GPU, independent full-table replicas" if world > 1 else "single GPU"),
                           "global_batch": world * B,
-                          "hipgraph": (not args.no_graph) and not sharded_mode,
+                          "hipgraph": ((not args.no_graph) and not sharded_mode) and
+                          ("one graph per %d-step cycle of resident batches" % n_batches if cycle else "one per step"),
                           "step": "sharded, de-duplicate first: per-column sort plan (next batch, second stream), all-to-all "
                           "of unique ids, owner gather, all-to-all of rows, fused fwd+bwd on them, per-id sums, all-to-all "
                           "of row gradients, owner rank-merge" if sharded_mode else

@@ -314,6 +314,48 @@ __global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ y, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// L2 on the embedding rows a batch used (5.DIN/ModelManager.py:176-190): factor * l2_loss(table[unique ids]),
+// l2_loss(x) = sum(x^2)/2.  rows_out[u,:] = factor * table[uniq_ids[u],:] (its gradient; zero on the padded tail),
+// per-workgroup partial sums of squares in a fixed order, then one workgroup adds the partials in order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2_rows_kernel(const float* __restrict__ table, int64_t ld, int E,
+                                                      const int64_t* __restrict__ uniq_ids,
+                                                      const int64_t* __restrict__ n_uniq, int64_t n, float factor,
+                                                      float* __restrict__ rows_out, float* __restrict__ partial) {
+  __shared__ float sh[4];
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float sq = 0.f;
+  if (t < n * E) {
+    int64_t u = t / E;
+    int d = (int)(t - u * E);
+    float x = 0.f;
+    if (u < *n_uniq) x = table[uniq_ids[u] * ld + d];
+    rows_out[t] = factor * x;
+    sq = x * x;
+  }
+  sq = wave_sum(sq);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sq;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(1024) void l2_final_kernel(const float* __restrict__ partial, int64_t nb, float factor,
+                                                        float* __restrict__ loss) {
+  __shared__ float sh[16];
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < nb; i += 1024) acc += partial[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += sh[q];
+    *loss = 0.5f * factor * s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K12 Adam
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ var, float* __restrict__ m,
@@ -660,6 +702,27 @@ extern "C" int rec_adam_rows_f32(float* var, int64_t ld, float* m, float* v, int
   if (cap == 0) return REC_OK;
   hipLaunchKernelGGL(adam_rows_lazy_kernel, dim3((unsigned)ceil_div64(cap * E, 256)), dim3(256), 0, as_stream(stream),
                      var, m, v, V, E, ld, uniq_ids, g_rows, n_uniq, cap, adam_lr_t(lr, b1, b2, t), b1, b2, eps);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" size_t rec_l2_rows_workspace_bytes(int64_t n, int E) {
+  if (n <= 0 || E <= 0) return 256;
+  return sizeof(float) * (size_t)ceil_div64(n * E, 256) + 256;
+}
+
+extern "C" int rec_l2_rows_f32(const float* table, int64_t ld, int64_t V, int E, const int64_t* uniq_ids,
+                               const int64_t* n_uniq, int64_t n, float factor, float* rows_out, float* loss,
+                               float* workspace, void* stream) {
+  if (V <= 0 || E <= 0 || ld < E || n < 0 || !loss) return REC_E_ARG;
+  hipStream_t st = as_stream(stream);
+  if (n == 0) return (int)hipMemsetAsync(loss, 0, sizeof(float), st);
+  if (!table || !uniq_ids || !n_uniq || !rows_out || !workspace) return REC_E_ARG;
+  int64_t nb = ceil_div64(n * E, 256);
+  hipLaunchKernelGGL(l2_rows_kernel, dim3((unsigned)nb), dim3(256), 0, st, table, ld, E, uniq_ids, n_uniq, n, factor,
+                     rows_out, workspace);
+  REC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(l2_final_kernel, dim3(1), dim3(1024), 0, st, workspace, nb, factor, loss);
   REC_LAUNCH_CHECK();
   return REC_OK;
 }

@@ -323,7 +323,11 @@ class DeepFMFusedStep:
 
     def _enqueue(self, cols, label, t, cur, have_plan, next_cols):
         """cur: plan buffer of this batch; have_plan: it was filled by the previous step; next_cols: columns of
-        the next batch, whose plan is built into the other buffer concurrently (second stream)."""
+        the next batch, whose plan is built into the other buffer concurrently (second stream).
+
+        The fork point is an event recorded BEFORE the fused kernel is enqueued, and the fused kernel is enqueued
+        first: in a captured graph both branches are roots, and the runtime starts them in creation order with
+        ~15 us between them -- the 37-us kernel of the critical path must be the one that goes first."""
         L = self.layer
         F, B, V = self.F, self.B, self.V
         arr = (C.c_void_p * F)(*[c.data_ptr() for c in cols])
@@ -331,12 +335,8 @@ class DeepFMFusedStep:
         side = self.side_stream
         forked = (not have_plan) or (next_cols is not None)
         if forked:
-            side.wait_stream(main)                               # fork: a sort only needs ids
-            with torch.cuda.stream(side):
-                if not have_plan:
-                    self._sort(cols, cur, side)                  # this batch's own plan (non-pipelined call)
-                if next_cols is not None:
-                    self._sort(next_cols, 1 - cur, side)         # the next batch's plan
+            fork_ev = torch.cuda.Event()
+            fork_ev.record(main)                                 # a sort only needs ids: nothing of this step
         st = C.c_void_p(main.cuda_stream)
         g = self.g
         emb = L.embed.embeddings
@@ -347,8 +347,15 @@ class DeepFMFusedStep:
             _p(g["MLP_layer1.kernel_1"]), _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]),
             _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(self.loss), _p(self.oob), _p(self.ws), st),
             "rec_deepfm_fused_fwd_bwd_f32")
-        if forked and not have_plan:
-            main.wait_stream(side)                               # this batch's plan is needed now
+        if forked:
+            side.wait_event(fork_ev)
+            with torch.cuda.stream(side):
+                if not have_plan:
+                    self._sort(cols, cur, side)                  # this batch's own plan (non-pipelined call)
+                if next_cols is not None:
+                    self._sort(next_cols, 1 - cur, side)         # the next batch's plan
+            if not have_plan:
+                main.wait_stream(side)                           # this batch's plan is needed now
         pl = self.plans[cur]
         check(lib.rec_colseg_sum_f32(_p(self.vals), _p(self.gz), _p(pl["perm"]), _p(pl["col_uid"]), _p(pl["col_seg"]),
                                      _p(pl["col_nu"]), B, F, _p(self.uniq_ids), _p(self.g_embed_rows),
@@ -418,6 +425,49 @@ class DeepFMFusedStep:
             ent[0].replay()
         if next_cols is not None:
             self._plan_key, self._plan_buf = next_key, 1 - cur
+        else:
+            self._plan_key = None
+        return self.loss
+
+    def many(self, batches, label_name="label", then=None):
+        """len(batches) consecutive train_loop iterations as ONE hipGraph replay (a launch-bound inner loop: one graph
+        launch costs ~20 us of idle GPU, a third of a step).  Step i announces batch i+1; the last one announces
+        ``then`` (usually the first batch of the next call).  Results left in the buffers are the last step's;
+        gradients are to be consumed by an optimizer captured in the same graph or after single-step calls."""
+        if not self.use_graph or self.optimizer is not None:
+            for i, b in enumerate(batches):
+                nxt = batches[i + 1] if i + 1 < len(batches) else then
+                self(b, label_name, next_inputs=nxt)
+            return self.loss
+        seq = [(self._cols(b), b[label_name]) for b in batches]
+        then_cols = self._cols(then) if then is not None else None
+        keys = [tuple(c.data_ptr() for c in cols) for cols, _ in seq]
+        then_key = tuple(c.data_ptr() for c in then_cols) if then_cols is not None else None
+        have_first = self._plan_key is not None and self._plan_key == keys[0]
+        cur0 = self._plan_buf if have_first else 0
+        gkey = ("many", tuple(keys), tuple(y.data_ptr() for _, y in seq), then_key, cur0, have_first)
+
+        def enqueue_all():
+            cur, have = cur0, have_first
+            for i, (cols, y) in enumerate(seq):
+                nxt = seq[i + 1][0] if i + 1 < len(seq) else then_cols
+                self._enqueue(cols, y, self.t, cur, have, nxt)
+                cur, have = 1 - cur, nxt is not None
+            return cur
+
+        ent = self._graphs.get(gkey)
+        if ent is None:
+            enqueue_all()                                        # warm-up (sets the kernel attributes)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                last = enqueue_all()
+            ent = (g, seq, then_cols, last)
+            self._graphs[gkey] = ent
+        ent[0].replay()
+        self.t += len(seq)
+        if then_cols is not None:
+            self._plan_key, self._plan_buf = then_key, ent[3]
         else:
             self._plan_key = None
         return self.loss

@@ -42,6 +42,25 @@ class Gather(torch.autograd.Function):
         return _sparse_grad(plan, g.contiguous().reshape(-1, E), E, (V, E)), None, None
 
 
+class UsedRowsL2(torch.autograd.Function):
+    """factor * tf.nn.l2_loss(tf.gather(table, tf.unique(ids).y))  (5.DIN/ModelManager.py:176-190): every row the
+    batch touched is penalised ONCE, however often it was looked up.  Backward: sparse rows factor * table[u]."""
+
+    @staticmethod
+    def forward(ctx, table, ids, factor):
+        V, E = table.shape
+        plan = ops.DedupPlan(ids.reshape(-1).contiguous(), V)
+        loss, rows = ops.l2_used_rows(table, plan, factor)
+        ctx.save_for_backward(plan.uniq_ids, rows, plan.n_uniq)
+        ctx.shape = (V, E)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        uniq_ids, rows, n_uniq = ctx.saved_tensors
+        return SparseRowGrad(uniq_ids, rows * g, n_uniq, ctx.shape).to_sparse(), None, None
+
+
 class EmbFM(torch.autograd.Function):
     """Fused w(X), embed(X), FM first + second order (K2+K3).  Returns z [B] and, for DeepFM, the gathered
     rows [B,F,E] that feed the DNN part.  Backward builds the IndexedSlices values (FM term + whatever came

@@ -81,7 +81,7 @@ class ModelManager:
     def __init__(self, feature_names=["user_tag1", "user_tag2", "item_tag1", "item_tag2", "item_tag3"],
                  json_path=None, data_info=None, embedding_dims=16, lr=0.00003, label_name="label", batch=100,
                  epochs=30, layer="fm_ranking", model_params={}, continuous_features=None,
-                 behavior_series_features=None, adam_sparse_mode="keras", device="cuda"):
+                 behavior_series_features=None, adam_sparse_mode="keras", device="cuda", regularization_factor=0.01):
         self.embedding_dims = embedding_dims
         self.lr = lr
         self.label_name = label_name
@@ -90,6 +90,7 @@ class ModelManager:
         self.model_params = dict(model_params)
         self.device = device
         self.adam_sparse_mode = adam_sparse_mode
+        self.regularization_factor = regularization_factor   # 5.DIN/ModelManager.py:20,38 (used by the DIN loop only)
         self.continuous_features = list(continuous_features or [])
         self.behavior_series_features = list(behavior_series_features or [])
         self.set_feature_names(feature_names, label_name)
@@ -189,12 +190,24 @@ class ModelManager:
             out[k] = t.to(self.device)
         return out
 
+    def used_rows_l2(self, inputs):
+        """5.DIN/ModelManager.py:176-190: ids of the user/context, item and (flattened) behaviour-series features in
+        one vector, tf.unique, then regularization_factor * l2_loss of those embedding rows."""
+        lay = self.model
+        parts = [inputs[f].reshape(-1) for f in list(lay.user_and_context_categorical_features) +
+                 list(lay.item_categorical_features) + list(lay.behavior_series_features)]
+        all_ids = torch.cat([p.to(torch.int64) for p in parts])
+        return Fn.UsedRowsL2.apply(lay.embed.embeddings, all_ids, self.regularization_factor)
+
     def train_loop(self, inputs):
-        """One iteration of 2.FM/ModelManager.py:171-181."""
+        """One iteration of 2.FM/ModelManager.py:171-181 (DIN: 5.DIN/ModelManager.py:170-197, which adds the L2 term
+        on the embedding rows the batch used)."""
         inputs = self._to_device(inputs)
         target = inputs.pop(self.label_name)
         logits = self.model(inputs)
         scaled_loss = self.loss(target, logits["output"])
+        if isinstance(self.model, CL.DINLayer) and self.regularization_factor:
+            scaled_loss = scaled_loss + self.used_rows_l2(inputs)
         scaled_loss.backward()
         self.opt.apply_gradients()
         self._metric_update(scaled_loss.item(), target, logits["output"])

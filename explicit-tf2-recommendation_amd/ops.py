@@ -162,6 +162,21 @@ class DedupPlan:
         return out
 
 
+def l2_used_rows(table, plan, factor):
+    """factor * l2_loss(table[unique ids of the plan]) (5.DIN/ModelManager.py:188-190) -> (loss [1], its gradient as
+    rows [n,E] aligned with plan.uniq_ids; zero beyond n_uniq)."""
+    _table(table, "table")
+    V, E = table.shape
+    n = plan.n
+    dev = table.device
+    rows = torch.empty((max(n, 1), E), dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.rec_l2_rows_workspace_bytes(n, E) // 4 + 1, dtype=torch.float32, device=dev)
+    check(lib.rec_l2_rows_f32(_ptr(table), table.stride(0), V, E, _ptr(plan.uniq_ids), _ptr(plan.n_uniq), n,
+                              float(factor), _ptr(rows), _ptr(loss), _ptr(ws), _stream()), "rec_l2_rows_f32")
+    return loss, rows
+
+
 # ---------------------------------------------------------------------------------------------------
 # dense
 # ---------------------------------------------------------------------------------------------------

@@ -176,6 +176,13 @@ int rec_adam_rows_f32(float* var, int64_t ld, float* m, float* v, int64_t V, int
                       const float* g_rows, const int64_t* n_uniq, int64_t cap, int64_t t, float lr,
                       float b1, float b2, float eps, void* stream);
 
+/* ---- L2 on the embedding rows a batch used (5.DIN/ModelManager.py:176-190):
+ * loss = factor * l2_loss(table[uniq_ids[0..n_uniq)]) with l2_loss(x) = sum(x^2)/2; rows_out [n,E] = its gradient
+ * factor * table[uniq_ids[u]] (zero rows on the padded tail u >= n_uniq).  uniq_ids / n_uniq: a rec_dedup_plan. */
+size_t rec_l2_rows_workspace_bytes(int64_t n, int E);
+int rec_l2_rows_f32(const float* table, int64_t ld, int64_t V, int E, const int64_t* uniq_ids, const int64_t* n_uniq,
+                    int64_t n, float factor, float* rows_out, float* loss, float* workspace, void* stream);
+
 /* ---- (e) row-wise block sharding of a table (no reference counterpart).
  * owner = id / rows_per_shard.  perm[n]: positions grouped by owner, ascending inside a group;
  * send_counts[n_shard] (int64); local_ids[n] = ids[perm] - owner*rows_per_shard. */

@@ -427,6 +427,14 @@ def bce_backward(y, p, dt=np.float32):
     return g / dt(p.size)
 
 
+def l2_used_rows(table, ids, factor, dt=np.float32):
+    """5.DIN/ModelManager.py:176-190: all ids of the batch in one vector, tf.unique, gather, factor * tf.nn.l2_loss
+    (= sum(x^2)/2).  Returns (loss, uniq ids ascending, d loss / d table[uniq] = factor * table[uniq])."""
+    uniq = np.unique(np.asarray(ids).reshape(-1))
+    rows = table[uniq].astype(dt)
+    return dt(factor) * dt(0.5) * np.square(rows).sum(dtype=dt), uniq, dt(factor) * rows
+
+
 def dedup_indexed_slices(indices, values, order="sorted"):
     """Sum rows of ``values`` that share an id.
 

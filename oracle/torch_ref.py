@@ -173,6 +173,13 @@ def din_forward(p, profile_ids, item_ids, series_ids, padding_index=0, mask_mode
     return torch.softmax(x @ p["out_k"] + p["out_b"], dim=-1), scores.squeeze(-1), pooled
 
 
+def l2_used_rows(table, ids, factor):
+    """5.DIN/ModelManager.py:176-190: tf.unique over every id of the batch, tf.gather, tf.nn.l2_loss * factor."""
+    uniq = torch.unique(ids.reshape(-1))
+    used = table[uniq]
+    return factor * 0.5 * torch.sum(used * used)
+
+
 def keras_bce(y, prob):
     """reduce_sum(BinaryCrossentropy()(y, prob)), 2.FM/ModelManager.py:100,175."""
     if prob.dim() == 1 and y.dim() == 2 and y.shape[1] == 1:

@@ -218,6 +218,38 @@ def test_fused_step_pipelined_plan(use_graph):
         assert close(g["MLP_layer1.kernel_0"].cpu().numpy(), ref["MLP_layer1.kernel_0"]), (cur, nxt)
 
 
+def test_fused_step_multi_step_graph_equals_single_steps():
+    """``many()``: several consecutive iterations captured as ONE hipGraph.  What is left in the buffers afterwards
+    must be bit-identical to running the same batches one call at a time -- for every prefix length, with and without
+    a ``then`` batch, entered with or without a prefetched plan."""
+    from explicit_tf2_recommendation_amd import engine, data
+    B, F, V = 1024, 26, 200000
+    layer, names, gen = make16(B, F, V, 29, "zipf")
+    devb = [data.to_device(gen.batch(B)) for _ in range(4)]
+    one = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, use_graph=False)
+    multi = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, use_graph=True)
+
+    def snapshot(step):
+        g = step.gradients()
+        nu = int(g["embed.embeddings"][2].item())
+        out = {k: v.clone() for k, v in g.items() if torch.is_tensor(v)}
+        out["ids"] = g["embed.embeddings"][0][:nu].clone()
+        out["rows"] = g["embed.embeddings"][1][:nu].clone()
+        out["wrows"] = g["w.embeddings"][1][:nu].clone()
+        out["loss"] = step.loss.clone()
+        return out
+
+    for seq, then in (([0, 1, 2, 3], 0), ([0, 1, 2, 3], 0), ([2, 1], None), ([3], 1), ([1, 0, 2], None)):
+        for i in seq:
+            one(devb[i])
+        want = snapshot(one)
+        multi.many([devb[i] for i in seq], then=devb[then] if then is not None else None)
+        multi.check_flags()
+        got = snapshot(multi)
+        for k in want:
+            assert torch.equal(want[k], got[k]), (seq, then, k)
+
+
 def test_fused_step_equals_generic_step_and_is_deterministic():
     from explicit_tf2_recommendation_amd import engine, data
     B, F, V = 4096, 26, 500000

@@ -95,3 +95,50 @@ def test_every_layer_family_trains():
     gen = data.SyntheticGenerator(user + item, V, series=ser, seq_len=12, seed=4)
     r1 = mm.train_step([gen.batch(B) for _ in range(3)])
     assert np.isfinite(r1["loss"])
+
+
+def test_din_train_loop_adds_l2_on_used_rows():
+    """5.DIN/ModelManager.py:176-192: loss = BCE + regularization_factor * l2_loss(embed[unique ids of the batch]);
+    the table gradient gains regularization_factor * embed[u] once per used row."""
+    from explicit_tf2_recommendation_amd import data, functional as Fn
+    from explicit_tf2_recommendation_amd.model_manager import ModelManager
+    from oracle import layers_np as L
+    user = ["uid", "utag1", "utag2", "utag3", "utag4"]
+    item = ["i_goods_id", "i_shop_id", "i_cate_id"]
+    ser = ["visited_goods_ids", "visited_shop_ids", "visited_cate_ids"]
+    V, B, E = 5000, 96, 8
+    kw = dict(feature_names=user + item, behavior_series_features=ser, data_info=data.data_info(V, 11),
+              embedding_dims=E, lr=0.01, batch=B, layer="din_layer",
+              model_params={"user_and_context_categorical_features": user, "item_categorical_features": item,
+                            "behavior_series_features": ser})
+    mm = ModelManager(regularization_factor=0.01, **kw)
+    with torch.no_grad():
+        mm.layer.embed.embeddings.mul_(10.0)
+    batch = data.SyntheticGenerator(user + item, V, series=ser, seq_len=12, seed=4).batch(B)
+    inputs = mm._to_device(dict(batch))
+    target = inputs.pop("label")
+    table = mm.layer.embed.embeddings.detach().cpu().numpy()
+    all_ids = np.concatenate([batch[f].reshape(-1) for f in user + item + ser])
+    l2_ref, uniq_ref, rows_ref = L.l2_used_rows(table.astype(np.float64), all_ids, 0.01, np.float64)
+    # the term alone: value and gradient through the C ABI
+    term = mm.used_rows_l2(inputs)
+    assert abs(term.item() - l2_ref) <= 1e-6 * max(1.0, abs(l2_ref))
+    term.backward()
+    g = mm.layer.embed.embeddings.grad.coalesce()
+    gi, gv = g.indices()[0].cpu().numpy(), g.values().cpu().numpy()
+    keep = np.abs(gv).sum(1) > 0
+    assert np.array_equal(gi[keep], uniq_ref[np.abs(rows_ref).sum(1) > 0])
+    dense = np.zeros_like(table, dtype=np.float64)
+    dense[gi] = gv
+    assert np.abs(dense[uniq_ref] - rows_ref).max() <= 1e-7
+    mm.layer.embed.embeddings.grad = None
+    # inside the loop: total loss = BCE + term
+    logits = mm.model(inputs)
+    bce = mm.loss(target, logits["output"]).item()
+    mm2 = ModelManager(regularization_factor=0.01, **kw)
+    mm2.model.load_state_dict(mm.model.state_dict())
+    total = mm2.train_loop(dict(batch)).item()
+    assert abs(total - (bce + l2_ref)) <= 2e-5 * max(1.0, abs(total))
+    mm3 = ModelManager(regularization_factor=0.0, **kw)
+    mm3.model.load_state_dict(mm.model.state_dict())
+    assert abs(mm3.train_loop(dict(batch)).item() - bce) <= 2e-5
