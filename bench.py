@@ -140,7 +140,7 @@ def main():
         step = engine.ShardedDeepFMStep(layer, B, gen.dims, gen.offsets)
     elif args.generic:
         step = engine.DeepFMTrainStep(layer, B, optimizer=None, use_graph=not args.no_graph)
-    else:   # 4 launches per step: fused fwd+bwd, reduction, per-column LDS sort (second stream), segment sums
+    else:   # per step: fused fwd+bwd kernel, reduction + segment sums (one launch), per-column sort on a second stream
         step = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, optimizer=None, use_graph=not args.no_graph)
 
     def barrier():
@@ -266,8 +266,8 @@ def main():
                            "the ceiling of this kernel is ~0.47 of the 8 TB/s spec in algorithmic bytes")
     roofline = roofline_gather
     if not args.generic:
-        # (2) the dominant kernel of the timed step: the fused forward+backward launch (+ its fixed-order reduction,
-        # same C call).  Algorithmic bytes: the gather above + labels + dL/dz + the IndexedSlices values it writes.
+        # (2) the dominant kernel of the timed step: the fused forward+backward kernel.  Algorithmic bytes: the gather
+        # above + labels + dL/dz + the IndexedSlices values it writes.
         fused_bytes = gather_bytes + B * 4 + B * 4 + B * F * E * 4
         fs = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, optimizer=None, use_graph=False)
         cols = [batches[0][k] for k in names]
@@ -277,18 +277,15 @@ def main():
         def launch_fused(n):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             for _ in range(n):
-                check(lib.rec_deepfm_fused_fwd_bwd_f32(
+                check(lib.rec_deepfm_fused_main_f32(
                     vp(emb), emb.stride(0), V, arr, F, B, vp(L.bias), vp(L.MLP_layer1.kernel_0),
                     vp(L.MLP_layer1.bias_0), vp(L.MLP_layer1.kernel_1), vp(L.MLP_layer1.bias_1),
                     vp(L.MLP_layer2.kernel_0), vp(L.MLP_layer2.bias_0), vp(batches[0]["label"]), vp(fs.gz),
-                    vp(fs.vals), None, vp(g["MLP_layer1.kernel_0"]), vp(g["MLP_layer1.bias_0"]),
-                    vp(g["MLP_layer1.kernel_1"]), vp(g["MLP_layer1.bias_1"]), vp(g["MLP_layer2.kernel_0"]),
-                    vp(g["MLP_layer2.bias_0"]), vp(g["bias"]), vp(fs.loss), vp(fs.oob), vp(fs.ws), st),
-                    "rec_deepfm_fused_fwd_bwd_f32")
+                    vp(fs.vals), None, vp(fs.oob), vp(fs.ws), st), "rec_deepfm_fused_main_f32")
 
-        roofline = roof("deepfm_fwd_bwd_kernel + deepfm_reduce_kernel (one C-ABI call: gather, FM, MLP on fp32 MFMA, BCE, "
-                        "backward, IndexedSlices values)", fused_bytes, timed(launch_fused, 50),
-                        ["deepfm_fwd_bwd_kernel", "deepfm_reduce_kernel"],
+        roofline = roof("deepfm_fwd_bwd_kernel (gather, FM, MLP on fp32 MFMA, BCE, backward, IndexedSlices values; its "
+                        "workgroup partials are reduced in the next launch)", fused_bytes, timed(launch_fused, 50),
+                        ["deepfm_fwd_bwd_kernel"],
                         "latency/sync-bound at one 122-KB workgroup per CU; 0.65 GFLOP of fp32 MFMA per launch is ~1% of "
                         "the matrix peak, so HBM is the binding roofline")
 
@@ -326,8 +323,8 @@ def main():
                           "of unique ids, owner gather, all-to-all of rows, fused fwd+bwd on them, per-id sums, all-to-all "
                           "of row gradients, owner rank-merge" if sharded_mode else
                           "generic" if args.generic else
-                          "fused: fwd+bwd kernel, reduce, segment sums; de-duplication plan of batch k+1 (per-column "
-                          "sort, second stream) overlaps step k"},
+                          "fused: fwd+bwd kernel, then reduction + segment sums in one launch; de-duplication plan of "
+                          "batch k+1 (per-column sort, second stream) overlaps step k"},
                "roofline": roofline, "roofline_gather": roofline_gather, "loss": loss}
         if replicas is not None:
             out["replicas_no_exchange"] = replicas

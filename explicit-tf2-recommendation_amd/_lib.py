@@ -50,6 +50,9 @@ SIGNATURES = {
     "rec_deepfm_fused_workspace_bytes": (sz, [i64, i32]),
     "rec_deepfm_fused_fwd_bwd_f32": (i32, [p, i64, i64, p, i32, i64, p, p, p, p, p, p, p, p, p, p, p, p, p, p, p, p, p,
                                            p, p, p, p, p]),
+    "rec_deepfm_fused_step_f32": (i32, [p, i64, i64, p, i32, i64] + [p] * 21 + [p] * 8 + [i32, p]),
+    "rec_deepfm_fused_main_f32": (i32, [p, i64, i64, p, i32, i64] + [p] * 13 + [p]),
+    "rec_deepfm_fused_post_f32": (i32, [i32, i64] + [p] * 19 + [i32, p]),
     "rec_colsort_workspace_bytes": (sz, [i64, i32]),
     "rec_colsort_plan_i64": (i32, [p, i32, i64, i64, p, i64, p, p, p, p, p, p, p]),
     "rec_colseg_sum_f32": (i32, [p, p, p, p, p, p, i64, i32, p, p, p, p, p]),

@@ -391,28 +391,35 @@ __global__ __launch_bounds__(256) void deepfm_fwd_bwd_kernel(Cols cols, FusedArg
 // fixed-order sum of the per-workgroup partials.  1024 threads = 16 slices x 64 lanes; lane owns 4 consecutive
 // outputs (float4), slice q adds workgroups q, q+16, q+32, ... (independent 16-B loads), then the 16 slices are
 // added in slice order through LDS.
-__global__ __launch_bounds__(1024) void deepfm_reduce_kernel(const float* __restrict__ dK0part, const float* __restrict__ small,
-                                                             int nwg, int D, int64_t B, float* __restrict__ dK0,
-                                                             float* __restrict__ dK1, float* __restrict__ db0,
-                                                             float* __restrict__ db1, float* __restrict__ dK2,
-                                                             float* __restrict__ db2, float* __restrict__ dbias,
-                                                             float* __restrict__ loss) {
+struct ReduceArgs {
+  const float* dK0part; const float* small; int nwg; int D; int64_t B;
+  float* dK0; float* dK1; float* db0; float* db1; float* dK2; float* db2; float* dbias; float* loss;
+};
+
+__device__ __forceinline__ void reduce_body(const ReduceArgs& r, int bidx) {
+  const float* __restrict__ dK0part = r.dK0part;
+  const float* __restrict__ small = r.small;
+  const int nwg = r.nwg, D = r.D;
+  const int64_t B = r.B;
+  float* __restrict__ dK0 = r.dK0; float* __restrict__ dK1 = r.dK1; float* __restrict__ db0 = r.db0;
+  float* __restrict__ db1 = r.db1; float* __restrict__ dK2 = r.dK2; float* __restrict__ db2 = r.db2;
+  float* __restrict__ dbias = r.dbias; float* __restrict__ loss = r.loss;
   __shared__ float4 red[16][64];
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int64_t n0 = (int64_t)D * U1;                  // multiple of 4
   const int nb0 = (int)((n0 / 4 + 63) / 64);           // blocks that cover dK0
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   int64_t e4 = 0;
-  bool is_small = (int)blockIdx.x >= nb0;
+  bool is_small = bidx >= nb0;
   if (!is_small) {
-    e4 = (int64_t)blockIdx.x * 64 + lane;              // float4 index into dK0
+    e4 = (int64_t)bidx * 64 + lane;                    // float4 index into dK0
     if (e4 * 4 < n0)
       for (int w = q; w < nwg; w += 16) {
         float4 x = *reinterpret_cast<const float4*>(dK0part + (int64_t)w * n0 + e4 * 4);
         acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
       }
   } else {
-    e4 = (int64_t)((int)blockIdx.x - nb0) * 64 + lane;  // float4 index into the SMALL block
+    e4 = (int64_t)(bidx - nb0) * 64 + lane;             // float4 index into the SMALL block
     if (e4 * 4 < SMALL)
       for (int w = q; w < nwg; w += 16) {
         float4 x = *reinterpret_cast<const float4*>(small + (int64_t)w * SMALL + e4 * 4);
@@ -444,6 +451,8 @@ __global__ __launch_bounds__(1024) void deepfm_reduce_kernel(const float* __rest
     else if (k == 305) loss[0] = sv[i] / (float)B;
   }
 }
+
+__global__ __launch_bounds__(1024) void deepfm_reduce_kernel(ReduceArgs r) { reduce_body(r, (int)blockIdx.x); }
 
 size_t fused_lds_bytes(int F) {
   size_t D = (size_t)F * E16;
@@ -584,32 +593,48 @@ __global__ __launch_bounds__(256) void colsort_rank_kernel(ColSortArgs a) {
     if (x[r] != PADW) a.sorted[(int64_t)f * a.B + pos[r]] = x[r];
 }
 
-template <int NPT>   // sorted positions per thread; 1024 threads cover NPT*1024 >= B
-__global__ __launch_bounds__(1024) void colsort_heads_kernel(const int64_t* __restrict__ col_lo, ColSortArgs a) {
-  __shared__ uint32_t last[1024];
-  __shared__ int wtot[16];
+// One workgroup per 1024 sorted positions of a column (grid nch x F, like the two kernels before it), so that ~200 CUs
+// share the work instead of F.  Every workgroup counts the run heads of the WHOLE column itself (B <= 16384 words out
+// of L2: heads before its slice = its rank offset, heads in all = col_nu) -- no second pass, no cross-workgroup wait.
+__global__ __launch_bounds__(256) void colsort_heads_kernel(const int64_t* __restrict__ col_lo, ColSortArgs a) {
+  __shared__ int wred[2][4];
+  __shared__ int wtot[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int f = blockIdx.x;
+  const int q = blockIdx.x, f = blockIdx.y;
   const int64_t B = a.B;
   const int64_t lo = col_lo[f];
-  uint32_t v[NPT];
-#pragma unroll
-  for (int r = 0; r < NPT; ++r) {
-    int64_t s = (int64_t)tid * NPT + r;
-    v[r] = s < B ? a.sorted[(int64_t)f * B + s] : PADW;
+  const uint32_t* srt = a.sorted + (int64_t)f * B;
+  const int pb = a.pos_bits;
+  const uint32_t pmask = (1u << pb) - 1u;
+  const int64_t s_begin = (int64_t)q * CHK;
+  // heads of the column before this slice / in total
+  int before = 0, all = 0;
+  for (int64_t s = tid; s < B; s += 256) {
+    int h = (s == 0 || (srt[s] >> pb) != (srt[s - 1] >> pb)) ? 1 : 0;
+    all += h;
+    if (s < s_begin) before += h;
   }
-  last[tid] = v[NPT - 1];
+  for (int o = 32; o > 0; o >>= 1) {
+    before += __shfl_xor(before, o, 64);
+    all += __shfl_xor(all, o, 64);
+  }
+  if (lane == 0) { wred[0][wave] = before; wred[1][wave] = all; }
   __syncthreads();
-  uint32_t prev = tid > 0 ? last[tid - 1] : PADW;
-  const uint32_t pmask = (1u << a.pos_bits) - 1u;
+  before = wred[0][0] + wred[0][1] + wred[0][2] + wred[0][3];
+  all = wred[1][0] + wred[1][1] + wred[1][2] + wred[1][3];
+  // own slice: thread owns 4 consecutive sorted positions
+  const int64_t s0 = s_begin + (int64_t)tid * 4;
+  uint32_t v[4];
+  bool hd[4];
   int heads = 0;
-  bool hd[NPT];
+  uint32_t prev = (s0 > 0 && s0 - 1 < B) ? srt[s0 - 1] : PADW;
 #pragma unroll
-  for (int r = 0; r < NPT; ++r) {
-    int64_t s = (int64_t)tid * NPT + r;
-    uint32_t pk = (r == 0 ? prev : v[r - 1]) >> a.pos_bits;
+  for (int r = 0; r < 4; ++r) {
+    int64_t s = s0 + r;
     bool valid = s < B;
-    hd[r] = valid && (s == 0 || (v[r] >> a.pos_bits) != pk);
+    v[r] = valid ? srt[s] : PADW;
+    uint32_t pk = (r == 0 ? prev : v[r - 1]) >> pb;
+    hd[r] = valid && (s == 0 || (v[r] >> pb) != pk);
     heads += hd[r] ? 1 : 0;
     if (valid) a.perm[(int64_t)f * B + s] = (int32_t)(v[r] & pmask);
   }
@@ -620,38 +645,48 @@ __global__ __launch_bounds__(1024) void colsort_heads_kernel(const int64_t* __re
   }
   if (lane == 63) wtot[wave] = incl;
   __syncthreads();
-  int woff = 0, total = 0;
-  for (int q = 0; q < 16; ++q) {
-    if (q < wave) woff += wtot[q];
-    total += wtot[q];
-  }
-  int rank = woff + incl - heads;
+  int woff = 0;
+  for (int w = 0; w < wave; ++w) woff += wtot[w];
+  int rank = before + woff + incl - heads;
 #pragma unroll
-  for (int r = 0; r < NPT; ++r) {
-    int64_t s = (int64_t)tid * NPT + r;
+  for (int r = 0; r < 4; ++r) {
+    int64_t s = s0 + r;
     if (hd[r]) {
-      a.col_uid[(int64_t)f * B + rank] = lo + (int64_t)(v[r] >> a.pos_bits);
+      a.col_uid[(int64_t)f * B + rank] = lo + (int64_t)(v[r] >> pb);
       a.col_seg[(int64_t)f * (B + 1) + rank] = (int32_t)s;
       ++rank;
     }
-    if (s < B && s + 1 >= total) a.col_seg[(int64_t)f * (B + 1) + s + 1] = (int32_t)B;   // tail [total .. B] = B
+    if (s < B && s + 1 >= all) a.col_seg[(int64_t)f * (B + 1) + s + 1] = (int32_t)B;   // tail [all .. B] = B
   }
-  if (tid == 0) a.col_nu[f] = total;
+  if (q == 0 && tid == 0) a.col_nu[f] = all;
 }
 
 // ------------------------------------------------------------------------------------------------
 // segment sums of both tables + global compaction.  One lane group (4 lanes x float4) per (column, local run).
 // Long runs: the first 16 rows per group directly; what is left of a long run is summed by the whole wave.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void colseg_sum_kernel(const float4* __restrict__ vals, const float* __restrict__ gz,
-                                                         const int32_t* __restrict__ perm, const int64_t* __restrict__ col_uid,
-                                                         const int32_t* __restrict__ col_seg, const int32_t* __restrict__ col_nu,
-                                                         int64_t B, int F, int64_t* __restrict__ uniq_ids,
-                                                         float4* __restrict__ g_embed, float* __restrict__ g_w,
-                                                         int64_t* __restrict__ n_uniq, int packed) {
+struct ColSegArgs {
+  const float4* vals; const float* gz; const int32_t* perm; const int64_t* col_uid; const int32_t* col_seg;
+  const int32_t* col_nu; int64_t B; int F; int64_t* uniq_ids; float4* g_embed; float* g_w; int64_t* n_uniq; int packed;
+};
+
+__device__ __forceinline__ void colseg_body(const ColSegArgs& k, int bidx) {
+  const float4* __restrict__ vals = k.vals;
+  const float* __restrict__ gz = k.gz;
+  const int32_t* __restrict__ perm = k.perm;
+  const int64_t* __restrict__ col_uid = k.col_uid;
+  const int32_t* __restrict__ col_seg = k.col_seg;
+  const int32_t* __restrict__ col_nu = k.col_nu;
+  const int64_t B = k.B;
+  const int F = k.F;
+  int64_t* __restrict__ uniq_ids = k.uniq_ids;
+  float4* __restrict__ g_embed = k.g_embed;
+  float* __restrict__ g_w = k.g_w;
+  int64_t* __restrict__ n_uniq = k.n_uniq;
+  const int packed = k.packed;
   const int tid = threadIdx.x, lane = tid & 63;
   const int c = tid & 3;                       // float4 chunk of the 16-float row
-  const int64_t grp = ((int64_t)blockIdx.x * 256 + tid) >> 2;      // (f, u_local) = (grp / B, grp % B)
+  const int64_t grp = ((int64_t)bidx * blockDim.x + tid) >> 2;     // (f, u_local) = (grp / B, grp % B)
   const int f = (int)(grp / B);
   const int u = (int)(grp - (int64_t)f * B);
   const bool in_range = f < F;
@@ -732,6 +767,15 @@ __global__ __launch_bounds__(256) void colseg_sum_kernel(const float4* __restric
   if (grp == 0 && c == 0) *n_uniq = total;
 }
 
+__global__ __launch_bounds__(256) void colseg_sum_kernel(ColSegArgs k) { colseg_body(k, (int)blockIdx.x); }
+
+// reduction of the workgroup partials and the segment sums only depend on the fused kernel, not on each other: one
+// launch, the first nb_reduce workgroups (1024 threads) reduce, the others sum segments -- they run side by side
+__global__ __launch_bounds__(1024) void deepfm_post_kernel(ReduceArgs r, ColSegArgs k, int nb_reduce) {
+  if ((int)blockIdx.x < nb_reduce) reduce_body(r, (int)blockIdx.x);
+  else colseg_body(k, (int)blockIdx.x - nb_reduce);
+}
+
 }  // namespace
 
 extern "C" size_t rec_deepfm_fused_workspace_bytes(int64_t B, int F) {
@@ -740,12 +784,12 @@ extern "C" size_t rec_deepfm_fused_workspace_bytes(int64_t B, int F) {
   return sizeof(float) * nwg * ((size_t)F * E16 * U1 + SMALL) + 256;
 }
 
-extern "C" int rec_deepfm_fused_fwd_bwd_f32(const float* table, int64_t ld, int64_t V, const int64_t* const* cols_host,
-                                            int F, int64_t B, const float* bias, const float* K0, const float* b0,
-                                            const float* K1, const float* b1, const float* K2, const float* b2,
-                                            const float* label, float* gz, float* vals, float* prob, float* dK0,
-                                            float* db0, float* dK1, float* db1, float* dK2, float* db2, float* dbias,
-                                            float* loss, int* oob_flag, void* workspace, void* stream) {
+static int launch_fused(const float* table, int64_t ld, int64_t V, const int64_t* const* cols_host, int F, int64_t B,
+                        const float* bias, const float* K0, const float* b0, const float* K1, const float* b1,
+                        const float* K2, const float* b2, const float* label, float* gz, float* vals, float* prob,
+                        float* dK0, float* db0, float* dK1, float* db1, float* dK2, float* db2, float* dbias,
+                        float* loss, int* oob_flag, void* workspace, void* stream, const ColSegArgs* seg,
+                        bool main_only = false) {
   if (B <= 0 || F <= 0 || V <= 0) return REC_E_ARG;
   if (ld != LD || F > 28 || F > REC_MAX_COLS || V >= (int64_t(1) << 31)) return REC_E_UNSUPPORTED;
   if (!table || !cols_host || !bias || !K0 || !b0 || !K1 || !b1 || !K2 || !b2 || !label || !gz || !vals || !dK0 ||
@@ -770,10 +814,84 @@ extern "C" int rec_deepfm_fused_fwd_bwd_f32(const float* table, int64_t ld, int6
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(deepfm_fwd_bwd_kernel, dim3(nwg), dim3(256), lds, st, cp, a);
   REC_LAUNCH_CHECK();
+  if (main_only) return REC_OK;
   int D = F * E16;
   unsigned nb = (unsigned)ceil_div64((int64_t)D * U1 / 4, 64) + (unsigned)ceil_div64(SMALL / 4, 64);
-  hipLaunchKernelGGL(deepfm_reduce_kernel, dim3(nb), dim3(1024), 0, st, dK0part, small, nwg, D, B, dK0, dK1, db0, db1,
-                     dK2, db2, dbias, loss);
+  ReduceArgs r{dK0part, small, nwg, D, B, dK0, dK1, db0, db1, dK2, db2, dbias, loss};
+  if (seg) {
+    unsigned nbs = (unsigned)ceil_div64(B * F * 4, 1024);
+    hipLaunchKernelGGL(deepfm_post_kernel, dim3(nb + nbs), dim3(1024), 0, st, r, *seg, (int)nb);
+  } else {
+    hipLaunchKernelGGL(deepfm_reduce_kernel, dim3(nb), dim3(1024), 0, st, r);
+  }
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_deepfm_fused_fwd_bwd_f32(const float* table, int64_t ld, int64_t V, const int64_t* const* cols_host,
+                                            int F, int64_t B, const float* bias, const float* K0, const float* b0,
+                                            const float* K1, const float* b1, const float* K2, const float* b2,
+                                            const float* label, float* gz, float* vals, float* prob, float* dK0,
+                                            float* db0, float* dK1, float* db1, float* dK2, float* db2, float* dbias,
+                                            float* loss, int* oob_flag, void* workspace, void* stream) {
+  return launch_fused(table, ld, V, cols_host, F, B, bias, K0, b0, K1, b1, K2, b2, label, gz, vals, prob, dK0, db0, dK1,
+                      db1, dK2, db2, dbias, loss, oob_flag, workspace, stream, nullptr);
+}
+
+extern "C" int rec_deepfm_fused_step_f32(const float* table, int64_t ld, int64_t V, const int64_t* const* cols_host,
+                                         int F, int64_t B, const float* bias, const float* K0, const float* b0,
+                                         const float* K1, const float* b1, const float* K2, const float* b2,
+                                         const float* label, float* gz, float* vals, float* prob, float* dK0, float* db0,
+                                         float* dK1, float* db1, float* dK2, float* db2, float* dbias, float* loss,
+                                         int* oob_flag, void* workspace, const int32_t* perm, const int64_t* col_uid,
+                                         const int32_t* col_seg, const int32_t* col_nu, int64_t* uniq_ids,
+                                         float* g_embed_rows, float* g_w_rows, int64_t* n_uniq, int packed,
+                                         void* stream) {
+  if (!perm || !col_uid || !col_seg || !col_nu || !uniq_ids || !g_embed_rows || !n_uniq || (!packed && !g_w_rows))
+    return REC_E_ARG;
+  if ((reinterpret_cast<uintptr_t>(vals) & 15) != 0 || (reinterpret_cast<uintptr_t>(g_embed_rows) & 15) != 0)
+    return REC_E_UNSUPPORTED;
+  ColSegArgs k{(const float4*)vals, gz, perm, col_uid, col_seg, col_nu, B, F, uniq_ids, (float4*)g_embed_rows,
+               packed ? (float*)nullptr : g_w_rows, n_uniq, packed ? 1 : 0};
+  return launch_fused(table, ld, V, cols_host, F, B, bias, K0, b0, K1, b1, K2, b2, label, gz, vals, prob, dK0, db0, dK1,
+                      db1, dK2, db2, dbias, loss, oob_flag, workspace, stream, &k);
+}
+
+// the two halves of rec_deepfm_fused_step_f32 as separate calls: a caller that builds the plan on another stream can
+// put its wait between them, so that only the second half depends on the plan
+extern "C" int rec_deepfm_fused_main_f32(const float* table, int64_t ld, int64_t V, const int64_t* const* cols_host,
+                                         int F, int64_t B, const float* bias, const float* K0, const float* b0,
+                                         const float* K1, const float* b1, const float* K2, const float* b2,
+                                         const float* label, float* gz, float* vals, float* prob, int* oob_flag,
+                                         void* workspace, void* stream) {
+  float dummy = 0.f;
+  float* d = &dummy;                      // gradient outputs are written by the second half only
+  return launch_fused(table, ld, V, cols_host, F, B, bias, K0, b0, K1, b1, K2, b2, label, gz, vals, prob, d, d, d, d, d,
+                      d, d, d, oob_flag, workspace, stream, nullptr, true);
+}
+
+extern "C" int rec_deepfm_fused_post_f32(int F, int64_t B, const float* gz, const float* vals, float* dK0, float* db0,
+                                         float* dK1, float* db1, float* dK2, float* db2, float* dbias, float* loss,
+                                         void* workspace, const int32_t* perm, const int64_t* col_uid,
+                                         const int32_t* col_seg, const int32_t* col_nu, int64_t* uniq_ids,
+                                         float* g_embed_rows, float* g_w_rows, int64_t* n_uniq, int packed,
+                                         void* stream) {
+  if (B <= 0 || F <= 0 || F > 28) return REC_E_ARG;
+  if (!gz || !vals || !dK0 || !db0 || !dK1 || !db1 || !dK2 || !db2 || !dbias || !loss || !workspace || !perm ||
+      !col_uid || !col_seg || !col_nu || !uniq_ids || !g_embed_rows || !n_uniq || (!packed && !g_w_rows))
+    return REC_E_ARG;
+  if ((reinterpret_cast<uintptr_t>(vals) & 15) != 0 || (reinterpret_cast<uintptr_t>(g_embed_rows) & 15) != 0)
+    return REC_E_UNSUPPORTED;
+  int nwg = (int)ceil_div64(B, EX);
+  int D = F * E16;
+  float* dK0part = (float*)workspace;
+  float* small = dK0part + (size_t)nwg * F * E16 * U1;
+  unsigned nb = (unsigned)ceil_div64((int64_t)D * U1 / 4, 64) + (unsigned)ceil_div64(SMALL / 4, 64);
+  unsigned nbs = (unsigned)ceil_div64(B * F * 4, 1024);
+  ReduceArgs r{dK0part, small, nwg, D, B, dK0, dK1, db0, db1, dK2, db2, dbias, loss};
+  ColSegArgs k{(const float4*)vals, gz, perm, col_uid, col_seg, col_nu, B, F, uniq_ids, (float4*)g_embed_rows,
+               packed ? (float*)nullptr : g_w_rows, n_uniq, packed ? 1 : 0};
+  hipLaunchKernelGGL(deepfm_post_kernel, dim3(nb + nbs), dim3(1024), 0, as_stream(stream), r, k, (int)nb);
   REC_LAUNCH_CHECK();
   return REC_OK;
 }
@@ -814,13 +932,7 @@ extern "C" int rec_colsort_plan_i64(const int64_t* const* cols_host, int F, int6
   REC_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsort_rank_kernel, dim3(nch, F), dim3(256), 0, st, a);
   REC_LAUNCH_CHECK();
-  switch (nch) {
-    case 1: hipLaunchKernelGGL(colsort_heads_kernel<1>, dim3(F), dim3(1024), 0, st, col_lo, a); break;
-    case 2: hipLaunchKernelGGL(colsort_heads_kernel<2>, dim3(F), dim3(1024), 0, st, col_lo, a); break;
-    case 4: hipLaunchKernelGGL(colsort_heads_kernel<4>, dim3(F), dim3(1024), 0, st, col_lo, a); break;
-    case 8: hipLaunchKernelGGL(colsort_heads_kernel<8>, dim3(F), dim3(1024), 0, st, col_lo, a); break;
-    default: hipLaunchKernelGGL(colsort_heads_kernel<16>, dim3(F), dim3(1024), 0, st, col_lo, a); break;
-  }
+  hipLaunchKernelGGL(colsort_heads_kernel, dim3(nch, F), dim3(256), 0, st, col_lo, a);
   REC_LAUNCH_CHECK();
   return REC_OK;
 }
@@ -834,9 +946,9 @@ extern "C" int rec_colseg_sum_f32(const float* vals, const float* gz, const int3
   if ((reinterpret_cast<uintptr_t>(vals) & 15) != 0 || (reinterpret_cast<uintptr_t>(g_embed_rows) & 15) != 0)
     return REC_E_UNSUPPORTED;
   int64_t groups = B * F;
-  hipLaunchKernelGGL(colseg_sum_kernel, dim3((unsigned)ceil_div64(groups * 4, 256)), dim3(256), 0, as_stream(stream),
-                     (const float4*)vals, gz, perm, col_uid, col_seg, col_nu, B, F, uniq_ids, (float4*)g_embed_rows,
-                     g_w_rows, n_uniq, 0);
+  ColSegArgs k{(const float4*)vals, gz, perm, col_uid, col_seg, col_nu, B, F, uniq_ids, (float4*)g_embed_rows,
+               g_w_rows, n_uniq, 0};
+  hipLaunchKernelGGL(colseg_sum_kernel, dim3((unsigned)ceil_div64(groups * 4, 256)), dim3(256), 0, as_stream(stream), k);
   REC_LAUNCH_CHECK();
   return REC_OK;
 }
@@ -849,9 +961,9 @@ extern "C" int rec_colseg_sum_packed_f32(const float* vals, const float* gz, con
   if ((reinterpret_cast<uintptr_t>(vals) & 15) != 0 || (reinterpret_cast<uintptr_t>(g_rows) & 15) != 0)
     return REC_E_UNSUPPORTED;
   int64_t groups = B * F;
-  hipLaunchKernelGGL(colseg_sum_kernel, dim3((unsigned)ceil_div64(groups * 4, 256)), dim3(256), 0, as_stream(stream),
-                     (const float4*)vals, gz, perm, col_uid, col_seg, col_nu, B, F, uniq_ids, (float4*)g_rows,
-                     (float*)nullptr, n_uniq, 1);
+  ColSegArgs k{(const float4*)vals, gz, perm, col_uid, col_seg, col_nu, B, F, uniq_ids, (float4*)g_rows,
+               (float*)nullptr, n_uniq, 1};
+  hipLaunchKernelGGL(colseg_sum_kernel, dim3((unsigned)ceil_div64(groups * 4, 256)), dim3(256), 0, as_stream(stream), k);
   REC_LAUNCH_CHECK();
   return REC_OK;
 }

@@ -321,13 +321,18 @@ class DeepFMFusedStep:
                                        _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.bad_ids),
                                        _p(self.sort_ws), C.c_void_p(stream.cuda_stream)), "rec_colsort_plan_i64")
 
-    def _enqueue(self, cols, label, t, cur, have_plan, next_cols):
+    def _enqueue(self, cols, label, t, cur, have_plan, next_cols, plan_ev=None, defer_join=False):
         """cur: plan buffer of this batch; have_plan: it was filled by the previous step; next_cols: columns of
         the next batch, whose plan is built into the other buffer concurrently (second stream).
 
-        The fork point is an event recorded BEFORE the fused kernel is enqueued, and the fused kernel is enqueued
-        first: in a captured graph both branches are roots, and the runtime starts them in creation order with
-        ~15 us between them -- the 37-us kernel of the critical path must be the one that goes first."""
+        Stream choreography (what a captured graph records as edges):
+          * the fork point is an event recorded BEFORE the fused kernel is enqueued, and the fused kernel is enqueued
+            first: in a captured graph both branches are roots and the runtime starts them in creation order with
+            ~15 us between them -- the 35-us kernel of the critical path must go first;
+          * only the second half of the step (reduction + segment sums) needs this batch's plan.  Inside a multi-step
+            graph the previous step hands over ``plan_ev`` (recorded on the second stream behind its sort) and this step
+            waits for it between the two halves; with ``defer_join`` this step in turn returns such an event instead of
+            joining the streams at its end, so the next fused kernel starts right behind this step's second half."""
         L = self.layer
         F, B, V = self.F, self.B, self.V
         arr = (C.c_void_p * F)(*[c.data_ptr() for c in cols])
@@ -340,13 +345,12 @@ class DeepFMFusedStep:
         st = C.c_void_p(main.cuda_stream)
         g = self.g
         emb = L.embed.embeddings
-        check(lib.rec_deepfm_fused_fwd_bwd_f32(
+        pl = self.plans[cur]
+        check(lib.rec_deepfm_fused_main_f32(
             _p(emb), emb.stride(0), V, arr, F, B, _p(L.bias), _p(L.MLP_layer1.kernel_0), _p(L.MLP_layer1.bias_0),
             _p(L.MLP_layer1.kernel_1), _p(L.MLP_layer1.bias_1), _p(L.MLP_layer2.kernel_0), _p(L.MLP_layer2.bias_0),
-            _p(label), _p(self.gz), _p(self.vals), None, _p(g["MLP_layer1.kernel_0"]), _p(g["MLP_layer1.bias_0"]),
-            _p(g["MLP_layer1.kernel_1"]), _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]),
-            _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(self.loss), _p(self.oob), _p(self.ws), st),
-            "rec_deepfm_fused_fwd_bwd_f32")
+            _p(label), _p(self.gz), _p(self.vals), None, _p(self.oob), _p(self.ws), st), "rec_deepfm_fused_main_f32")
+        out_ev = None
         if forked:
             side.wait_event(fork_ev)
             with torch.cuda.stream(side):
@@ -354,16 +358,25 @@ class DeepFMFusedStep:
                     self._sort(cols, cur, side)                  # this batch's own plan (non-pipelined call)
                 if next_cols is not None:
                     self._sort(next_cols, 1 - cur, side)         # the next batch's plan
+                if defer_join and next_cols is not None:
+                    out_ev = torch.cuda.Event()
+                    out_ev.record(side)
             if not have_plan:
                 main.wait_stream(side)                           # this batch's plan is needed now
-        pl = self.plans[cur]
-        check(lib.rec_colseg_sum_f32(_p(self.vals), _p(self.gz), _p(pl["perm"]), _p(pl["col_uid"]), _p(pl["col_seg"]),
-                                     _p(pl["col_nu"]), B, F, _p(self.uniq_ids), _p(self.g_embed_rows),
-                                     _p(self.g_w_rows), _p(self.n_uniq), st), "rec_colseg_sum_f32")
+        if plan_ev is not None:
+            main.wait_event(plan_ev)                             # the plan built beside the previous step
+        # reduction of the workgroup partials and the segment sums side by side in ONE launch
+        check(lib.rec_deepfm_fused_post_f32(
+            F, B, _p(self.gz), _p(self.vals), _p(g["MLP_layer1.kernel_0"]), _p(g["MLP_layer1.bias_0"]),
+            _p(g["MLP_layer1.kernel_1"]), _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]),
+            _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(self.loss), _p(self.ws), _p(pl["perm"]), _p(pl["col_uid"]),
+            _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.uniq_ids), _p(self.g_embed_rows), _p(self.g_w_rows),
+            _p(self.n_uniq), 0, st), "rec_deepfm_fused_post_f32")
         if self.optimizer is not None:
             self._optimizer(t, st)
-        if forked and have_plan:
+        if forked and have_plan and out_ev is None:
             main.wait_stream(side)                               # join: the next step may rely on the other buffer
+        return out_ev
 
     def _optimizer(self, t, st):
         lr, b1, b2, eps = self.lr, 0.9, 0.999, 1e-7
@@ -448,10 +461,11 @@ class DeepFMFusedStep:
         gkey = ("many", tuple(keys), tuple(y.data_ptr() for _, y in seq), then_key, cur0, have_first)
 
         def enqueue_all():
-            cur, have = cur0, have_first
+            cur, have, ev = cur0, have_first, None
             for i, (cols, y) in enumerate(seq):
-                nxt = seq[i + 1][0] if i + 1 < len(seq) else then_cols
-                self._enqueue(cols, y, self.t, cur, have, nxt)
+                last = i + 1 == len(seq)
+                nxt = seq[i + 1][0] if not last else then_cols
+                ev = self._enqueue(cols, y, self.t, cur, have, nxt, plan_ev=ev, defer_join=not last)
                 cur, have = 1 - cur, nxt is not None
             return cur
 
@@ -602,25 +616,29 @@ class HipStepBackend:
 
     def rows_step(self, pl, rows_local, y):
         """The fused forward+backward kernel on the exchanged rows: the local [n_uniq,32] buffer is the "table" and
-        the ids are the compact indices uidx.  Fills step.g / step.loss; returns (vals [n,16], gz [B])."""
+        the ids are the compact indices uidx.  Returns (vals [n,16], gz [B]); the dense gradients follow in
+        local_grad (the reduction shares its launch with the segment sums)."""
         st_ = self.step
-        L, g = st_.layer, st_.g
-        check(lib.rec_deepfm_fused_fwd_bwd_f32(
+        L = st_.layer
+        check(lib.rec_deepfm_fused_main_f32(
             _p(rows_local), 32, rows_local.shape[0], pl["uidx_arr"], st_.F, st_.B, _p(L.bias),
             _p(L.MLP_layer1.kernel_0), _p(L.MLP_layer1.bias_0), _p(L.MLP_layer1.kernel_1), _p(L.MLP_layer1.bias_1),
-            _p(L.MLP_layer2.kernel_0), _p(L.MLP_layer2.bias_0), _p(y), _p(self.gz), _p(self.vals), None,
-            _p(g["MLP_layer1.kernel_0"]), _p(g["MLP_layer1.bias_0"]), _p(g["MLP_layer1.kernel_1"]),
-            _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]), _p(g["MLP_layer2.bias_0"]), _p(g["bias"]),
-            _p(st_.loss), _p(st_.oob), _p(self.ws), self.st), "rec_deepfm_fused_fwd_bwd_f32")
+            _p(L.MLP_layer2.kernel_0), _p(L.MLP_layer2.bias_0), _p(y), _p(self.gz), _p(self.vals), None, _p(st_.oob),
+            _p(self.ws), self.st), "rec_deepfm_fused_main_f32")
         return self.vals, self.gz
 
     def local_grad(self, pl, vals, gz):
-        """This batch's gradient per unique id as rows [embed 16 | w | 0 0 0] ([n,20]; first n_uniq rows, ascending
-        id = send order)."""
+        """Reduction of the workgroup partials (fills step.g / step.loss) and, in the same launch, this batch's
+        gradient per unique id as rows [embed 16 | w | 0 0 0] ([n,20]; first n_uniq rows, ascending id = send
+        order)."""
         st_ = self.step
-        check(lib.rec_colseg_sum_packed_f32(_p(vals), _p(gz), _p(pl["perm"]), _p(pl["col_uid"]), _p(pl["col_seg"]),
-                                            _p(pl["col_nu"]), st_.B, st_.F, _p(self.uniq_ids), _p(self.grows),
-                                            _p(self.n_uniq), self.st), "rec_colseg_sum_packed_f32")
+        g = st_.g
+        check(lib.rec_deepfm_fused_post_f32(
+            st_.F, st_.B, _p(gz), _p(vals), _p(g["MLP_layer1.kernel_0"]), _p(g["MLP_layer1.bias_0"]),
+            _p(g["MLP_layer1.kernel_1"]), _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]),
+            _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(st_.loss), _p(self.ws), _p(pl["perm"]), _p(pl["col_uid"]),
+            _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.uniq_ids), _p(self.grows), None, _p(self.n_uniq), 1, self.st),
+            "rec_deepfm_fused_post_f32")
         return self.grows
 
     def _owner_buffers(self, m):

@@ -214,6 +214,28 @@ int rec_deepfm_fused_fwd_bwd_f32(const float* table, int64_t ld, int64_t V, cons
                                  const float* b1, const float* K2, const float* b2, const float* label, float* gz,
                                  float* vals, float* prob, float* dK0, float* db0, float* dK1, float* db1, float* dK2,
                                  float* db2, float* dbias, float* loss, int* oob_flag, void* workspace, void* stream);
+/* The same iteration when the de-duplication plan of the batch (rec_colsort_plan_i64) already exists: the fused kernel,
+ * then ONE launch in which the reduction of the workgroup partials and the segment sums of rec_colseg_sum_f32 (packed:
+ * of rec_colseg_sum_packed_f32, g_embed_rows [B*F,20], g_w_rows unused) run side by side. */
+int rec_deepfm_fused_step_f32(const float* table, int64_t ld, int64_t V, const int64_t* const* cols_host, int F,
+                              int64_t B, const float* bias, const float* K0, const float* b0, const float* K1,
+                              const float* b1, const float* K2, const float* b2, const float* label, float* gz,
+                              float* vals, float* prob, float* dK0, float* db0, float* dK1, float* db1, float* dK2,
+                              float* db2, float* dbias, float* loss, int* oob_flag, void* workspace,
+                              const int32_t* perm, const int64_t* col_uid, const int32_t* col_seg,
+                              const int32_t* col_nu, int64_t* uniq_ids, float* g_embed_rows, float* g_w_rows,
+                              int64_t* n_uniq, int packed, void* stream);
+/* The two halves of rec_deepfm_fused_step_f32 as separate calls (fused kernel | reduction + segment sums): a caller
+ * that builds the plan on another stream puts its wait between them, so that only the second half depends on it. */
+int rec_deepfm_fused_main_f32(const float* table, int64_t ld, int64_t V, const int64_t* const* cols_host, int F,
+                              int64_t B, const float* bias, const float* K0, const float* b0, const float* K1,
+                              const float* b1, const float* K2, const float* b2, const float* label, float* gz,
+                              float* vals, float* prob, int* oob_flag, void* workspace, void* stream);
+int rec_deepfm_fused_post_f32(int F, int64_t B, const float* gz, const float* vals, float* dK0, float* db0, float* dK1,
+                              float* db1, float* dK2, float* db2, float* dbias, float* loss, void* workspace,
+                              const int32_t* perm, const int64_t* col_uid, const int32_t* col_seg,
+                              const int32_t* col_nu, int64_t* uniq_ids, float* g_embed_rows, float* g_w_rows,
+                              int64_t* n_uniq, int packed, void* stream);
 /* De-duplication plan that uses the DataGenerator contract (2.FM/DataGenerator.py:76-88): column f only holds ids of
  * [col_lo[f], col_lo[f] + 2^key_bits) and columns are given in ascending range order, so duplicates occur only inside
  * a column and each column (B <= 16384 ids; max_key = largest id - col_lo over all columns, bits(max_key) +
