@@ -27,6 +27,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int EX = 32;        // examples per workgroup
 constexpr int E16 = 16;       // embedding dims
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void deepfm_fwd_bwd_kernel(Cols cols, FusedArg
   float* b0s = K1s + U1 * U2;            // [32]
   float* b1s = b0s + U1;                 // [8]
   float* K2s = b1s + U2;                 // [8]
-  float* TRS = K2s + U2;                 // [4 waves][16][20]  accumulator tile transposed for 16-byte stores
+  float* PT = K2s + U2;                  // [4 waves][EX][HS]  K-split partial tiles of layer 1 (P3)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t ex0 = (int64_t)blockIdx.x * EX;
@@ -179,34 +180,57 @@ __global__ __launch_bounds__(256) void deepfm_fwd_bwd_kernel(Cols cols, FusedArg
   __syncthreads();                         // Wl / ids are dead from here on: their LDS becomes H1s / DP1
   if (a.stop == 3) return;
 
-  // ---- P3: h1 = relu(X . K0 + b0) on the matrix cores.  wave = (example tile et, unit half nh)
-  const int et = wave >> 1, nh = wave & 1;
-  const int l15 = lane & 15, g = lane >> 4;
+  // ---- P3: h1 = relu(X . K0 + b0) on the matrix cores, 32x32x2 tiles.  The output is ONE 32x32 tile, so the four
+  // waves split K = 16F: wave w multiplies columns [4F*w, 4F*(w+1)) of X with the matching rows of K0 (2F steps of 2),
+  // the four partial tiles meet in LDS and are added in wave order.  Lane l: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];
+  // D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
+  const int lo = lane & 31, hi = lane >> 5;
   {
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const float* ap = XT + (et * 16 + l15) * XS + g;
-    const float* bp = K0s + g * HS + nh * 16 + l15;
-    const int nk = D / 4;                                    // = 4F: a multiple of 4
-    float an[4], bn[4];
+    f32x16 acc;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { an[u] = ap[4 * u]; bn[u] = bp[4 * u * HS]; }
-    for (int k0 = 0; k0 < nk; k0 += 4) {
-      float ac[4], bc[4];
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int kbeg = wave * 4 * F;
+    const float* ap = XT + lo * XS + kbeg + hi;              // + 2*step
+    const float* bp = K0s + (kbeg + hi) * HS + lo;           // + 2*step*HS
+    const int ns = 2 * F;                                    // steps of this wave
+    // groups of 4 steps, software-pipelined with a STATIC number of LDS loads in flight (no guarded loads: a guard
+    // makes the count of outstanding loads unknown to the compiler, which then waits for all of them before the
+    // first MFMA of every group); the last group and the 2-step tail of an odd F are peeled
+    const int ng = ns >> 2;
+    float ac[4], bc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { ac[u] = ap[2 * u]; bc[u] = bp[2 * u * HS]; }      // F >= 2: group 0 exists
+    for (int gi = 0; gi + 1 < ng; ++gi) {
+      float an[4], bn[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        an[u] = ap[2 * (4 * (gi + 1) + u)];
+        bn[u] = bp[2 * (4 * (gi + 1) + u) * HS];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u], acc, 0, 0, 0);
 #pragma unroll
       for (int u = 0; u < 4; ++u) { ac[u] = an[u]; bc[u] = bn[u]; }
-      if (k0 + 4 < nk) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { an[u] = ap[4 * (k0 + 4 + u)]; bn[u] = bp[4 * (k0 + 4 + u) * HS]; }
-      }
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[0], bc[0], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[1], bc[1], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[2], bc[2], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[3], bc[3], acc1, 0, 0, 0);
     }
-    f32x4 acc = acc0 + acc1;
-    float bb = b0s[nh * 16 + l15];
+    if (ng > 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) H1s[(et * 16 + 4 * g + r) * HS + nh * 16 + l15] = fmaxf(acc[r] + bb, 0.f);
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u], acc, 0, 0, 0);
+    }
+    for (int sn = 4 * ng; sn < ns; ++sn)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * sn], bp[2 * sn * HS], acc, 0, 0, 0);
+    float* pt = PT + wave * (EX * HS);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pt[((r & 3) + 8 * (r >> 2) + 4 * hi) * HS + lo] = acc[r];
+  }
+  __syncthreads();
+  {
+    const int e = tid >> 3, u4 = (tid & 7) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int o = e * HS + u4 + q;
+      float h = ((PT[o] + PT[EX * HS + o]) + PT[2 * EX * HS + o]) + PT[3 * EX * HS + o];     // wave order: fixed
+      H1s[o] = fmaxf(h + b0s[u4 + q], 0.f);
+    }
   }
   __syncthreads();
   if (a.stop == 4) return;
@@ -216,6 +240,7 @@ __global__ __launch_bounds__(256) void deepfm_fwd_bwd_kernel(Cols cols, FusedArg
     const int e = tid >> 3, u = tid & 7;
     const bool valid = e < n_ex;
     float h2 = b1s[u];
+#pragma unroll
     for (int k = 0; k < U1; ++k) h2 += H1s[e * HS + k] * K1s[k * U2 + u];
     h2 = fmaxf(h2, 0.f);
     float dnn = h2 * K2s[u];
@@ -257,26 +282,31 @@ __global__ __launch_bounds__(256) void deepfm_fwd_bwd_kernel(Cols cols, FusedArg
   }
   __syncthreads();
 
-  // ---- small per-workgroup partials (fixed order over the 32 examples)
+  // ---- small per-workgroup partials (fixed order over the 32 examples).  The single-thread sums are spread over the
+  // four waves (no barrier follows: a wave goes on to P5 as soon as its own share is stored)
   {
     float* sm = a.small + (int64_t)blockIdx.x * SMALL;
     const int k = tid >> 3, u = tid & 7;
     float s = 0.f;
+#pragma unroll 8
     for (int e = 0; e < EX; ++e) s += H1s[e * HS + k] * dp2s[e * U2 + u];
     sm[tid] = s;                                             // dK1 [32][8]
-    if (tid < U1) {
+    if (wave == 1 && lane < U1) {
       float t = 0.f;
-      for (int e = 0; e < EX; ++e) t += DP1[e * HS + tid];
-      sm[256 + tid] = t;                                     // db0
+#pragma unroll 8
+      for (int e = 0; e < EX; ++e) t += DP1[e * HS + lane];
+      sm[256 + lane] = t;                                    // db0
     }
-    if (tid < U2) {
+    if (wave == 2 && lane < U2) {
       float t1 = 0.f, t2 = 0.f;
-      for (int e = 0; e < EX; ++e) { t1 += dp2s[e * U2 + tid]; t2 += h2s[e * U2 + tid] * dzs[e]; }
-      sm[288 + tid] = t1;                                    // db1
-      sm[296 + tid] = t2;                                    // dK2
+#pragma unroll 8
+      for (int e = 0; e < EX; ++e) { t1 += dp2s[e * U2 + lane]; t2 += h2s[e * U2 + lane] * dzs[e]; }
+      sm[288 + lane] = t1;                                   // db1
+      sm[296 + lane] = t2;                                   // dK2
     }
-    if (tid == 0) {
+    if (wave == 3 && lane == 0) {
       float t1 = 0.f, t2 = 0.f;
+#pragma unroll 8
       for (int e = 0; e < EX; ++e) { t1 += dzs[e]; t2 += lss[e]; }
       sm[304] = t1;                                          // db2 = dbias
       sm[305] = t2;                                          // sum of per-example BCE terms
@@ -285,104 +315,78 @@ __global__ __launch_bounds__(256) void deepfm_fwd_bwd_kernel(Cols cols, FusedArg
 
   if (a.stop == 5) return;
 
-  // ---- P5: dX = dpre1 . K0^T on the matrix cores, fused with the IndexedSlices values.  fields split by nh
+  // ---- P5: dX = dpre1 . K0^T on the matrix cores, fused with the IndexedSlices values.  N = 16F is cut into tiles of
+  // 32 columns = two fields; wave w takes tiles w, w+4, ...; K = 32 units = 16 steps.  A (dpre1, the same for every
+  // tile) stays in registers.  D rows are examples, columns 32 consecutive floats of the example's values row: every
+  // accumulator register leaves as two full 128-byte lines, no transpose.
+  const int n_tiles = (F + 1) / 2;
   {
-    const int f_lo = nh * ((F + 1) / 2), f_hi = nh ? F : (F + 1) / 2;
-    const float* ap = DP1 + (et * 16 + l15) * HS + g;
-    float av[U1 / 4];
+    float av[16], dzr[16], sr[16];
 #pragma unroll
-    for (int kk = 0; kk < U1 / 4; ++kk) av[kk] = ap[4 * kk];
-    float bn[U1 / 4];
-    {
-      const float* bp = K0s + (f_lo * E16 + l15) * HS + g;
+    for (int s2 = 0; s2 < 16; ++s2) av[s2] = DP1[lo * HS + 2 * s2 + hi];
 #pragma unroll
-      for (int kk = 0; kk < U1 / 4; ++kk) bn[kk] = f_lo < f_hi ? bp[4 * kk] : 0.f;
+    for (int r = 0; r < 16; ++r) {
+      int e = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      dzr[r] = dzs[e];
+      sr[r] = Ss[e * E16 + (lo & 15)];
     }
-    for (int f = f_lo; f < f_hi; ++f) {
-      float bc[U1 / 4];
+    for (int t = wave; t < n_tiles; t += 4) {
+      const float* bp = K0s + (t * 32 + lo) * HS + hi;       // B[k = unit 2s+hi][n = lo] = K0[t*32 + lo][2s + hi]
+      const float* xp = XT + (4 * hi) * XS + t * 32 + lo;    // x of (row r, this lane): + ((r&3) + 8*(r>>2)) * XS
+      f32x16 acc;
 #pragma unroll
-      for (int kk = 0; kk < U1 / 4; ++kk) bc[kk] = bn[kk];
-      if (f + 1 < f_hi) {
-        const float* bp = K0s + ((f + 1) * E16 + l15) * HS + g;
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      float bv[16], xv[16];
 #pragma unroll
-        for (int kk = 0; kk < U1 / 4; ++kk) bn[kk] = bp[4 * kk];
-      }
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      for (int s2 = 0; s2 < 16; ++s2) bv[s2] = bp[2 * s2];
 #pragma unroll
-      for (int kk = 0; kk < U1 / 4; kk += 2) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bc[kk], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk + 1], bc[kk + 1], acc1, 0, 0, 0);
-      }
-      f32x4 acc = acc0 + acc1;
-      // accumulator tile (row = example 4g+r, col = dim l15) -> LDS -> one row quarter per lane, so that the
-      // IndexedSlices values leave as 16-byte stores (64 lanes x 16 B = sixteen full 64-B rows per instruction)
-      float* tr = TRS + wave * (16 * 20);
+      for (int r = 0; r < 16; ++r) xv[r] = xp[((r & 3) + 8 * (r >> 2)) * XS];     // all loads before the first MFMA
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tr[(4 * g + r) * 20 + l15] = acc[r];
-      const int row = lane >> 2, c4 = lane & 3;
-      float4 dx = *reinterpret_cast<const float4*>(tr + row * 20 + 4 * c4);
-      int e = et * 16 + row;
-      if (e < n_ex) {
-        const float* xp = XT + e * XS + f * E16 + 4 * c4;
-        float2 x01 = reinterpret_cast<const float2*>(xp)[0], x23 = reinterpret_cast<const float2*>(xp)[1];
-        float4 sv = *reinterpret_cast<const float4*>(Ss + e * E16 + 4 * c4);
-        float dzv = dzs[e];
-        float4 o = make_float4(dzv * (sv.x - x01.x) + dx.x, dzv * (sv.y - x01.y) + dx.y, dzv * (sv.z - x23.x) + dx.z,
-                               dzv * (sv.w - x23.y) + dx.w);
-        *reinterpret_cast<float4*>(a.vals + ((ex0 + e) * F + f) * E16 + 4 * c4) = o;
+      for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc, 0, 0, 0);
+      float* vp = a.vals + ((ex0 + 4 * hi) * F + 2 * t) * E16 + lo;
+      if (n_ex == EX && 2 * t + 1 < F) {                     // whole tile inside the batch and the fields: no guards
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          vp[(int64_t)((r & 3) + 8 * (r >> 2)) * F * E16] = dzr[r] * (sr[r] - xv[r]) + acc[r];
+      } else if (2 * t + (lo >> 4) < F) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int e = (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (e < n_ex) vp[(int64_t)((r & 3) + 8 * (r >> 2)) * F * E16] = dzr[r] * (sr[r] - xv[r]) + acc[r];
+        }
       }
     }
   }
 
   if (a.stop == 6) return;
 
-  // ---- P6: per-workgroup dK0 = X^T . dpre1 on the matrix cores.  wave (et, nh) covers all fields for its 16 examples
+  // ---- P6: per-workgroup dK0 = X^T . dpre1 on the matrix cores.  M = 16F rows of K0 in tiles of 32, wave w takes tiles
+  // w, w+4, ...; K = the 32 examples = 16 steps; B (dpre1) stays in registers.  P5 and P6 only read LDS: no barrier.
   {
     float* part = a.dK0part + (int64_t)blockIdx.x * D * U1;
-    constexpr int MAXF = 28;
-    f32x4 acc[MAXF];
+    float bv[16];
 #pragma unroll
-    for (int f = 0; f < MAXF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s2 = 0; s2 < 16; ++s2) bv[s2] = DP1[(2 * s2 + hi) * HS + lo];
+    for (int t = wave; t < n_tiles; t += 4) {
+      // A[i = row lo of the tile][k = example 2s+hi].  For an odd F the upper half of the last tile does not exist:
+      // those lanes read the start of the next LDS row instead, which only reaches D rows that are never stored
+      const float* ap = XT + hi * XS + t * 32 + lo;
+      f32x16 acc;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      float bv = DP1[(et * 16 + 4 * kk + g) * HS + nh * 16 + l15];
-      const float* ap = XT + (et * 16 + 4 * kk + g) * XS + l15;
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      float xv[16];
 #pragma unroll
-      for (int f = 0; f < MAXF; ++f)
-        if (f < F) acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[f * E16], bv, acc[f], 0, 0, 0);
-    }
-    __syncthreads();                                         // all reads of XT / K0s are done: reuse them as scratch
-    // the two example tiles of a unit half add up: tile 0's wave finalises fields [0, Fh), tile 1's wave [Fh, F);
-    // each first hands the other half of its accumulators over through LDS
-    const int Fh = (F + 1) / 2;
-    const int xs = 4 * Fh + 1;
-    float* mine = XT + (wave * 64 + lane) * xs;                       // written by me, read by my partner
-    const float* theirs = XT + ((wave ^ 2) * 64 + lane) * xs;         // partner = same nh, other example tile
+      for (int s2 = 0; s2 < 16; ++s2) xv[s2] = ap[2 * s2 * XS];
 #pragma unroll
-    for (int f = 0; f < MAXF; ++f) {
-      bool give = et == 0 ? (f >= Fh && f < F) : (f < Fh);
-      if (give) {
-        int slot = et == 0 ? f - Fh : f;
+      for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[s2], bv[s2], acc, 0, 0, 0);
+      float* pp = part + (t * 32 + 4 * hi) * U1 + lo;
+      if (t * 32 + 32 <= D) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mine[slot * 4 + r] = acc[f][r];
-      }
-    }
-    __syncthreads();
-    float* tr = TRS + wave * (16 * 20);
-    const int row = lane >> 2, c4 = lane & 3;
+        for (int r = 0; r < 16; ++r) pp[((r & 3) + 8 * (r >> 2)) * U1] = acc[r];
+      } else {
 #pragma unroll
-    for (int f = 0; f < MAXF; ++f) {
-      bool keep = et == 0 ? (f < Fh) : (f >= Fh && f < F);
-      if (keep) {
-        int slot = et == 0 ? f : f - Fh;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float t0 = et == 0 ? acc[f][r] : theirs[slot * 4 + r];      // tile 0's term first: fixed order
-          float t1 = et == 0 ? theirs[slot * 4 + r] : acc[f][r];
-          tr[(4 * g + r) * 20 + l15] = t0 + t1;                        // (row = dim 4g+r, col = unit l15)
-        }
-        float4 o = *reinterpret_cast<const float4*>(tr + row * 20 + 4 * c4);   // one row quarter per lane
-        *reinterpret_cast<float4*>(part + (f * E16 + row) * U1 + nh * 16 + 4 * c4) = o;
+        for (int r = 0; r < 16; ++r)
+          if (t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi < D) pp[((r & 3) + 8 * (r >> 2)) * U1] = acc[r];
       }
     }
   }
@@ -457,9 +461,7 @@ __global__ __launch_bounds__(1024) void deepfm_reduce_kernel(ReduceArgs r) { red
 size_t fused_lds_bytes(int F) {
   size_t D = (size_t)F * E16;
   size_t f = (size_t)EX * (D + 2) + D * HS + 2 * (size_t)EX * HS + (size_t)EX * E16 + 2 * (size_t)EX * U2 +
-             3 * (size_t)EX + U1 * U2 + U1 + 2 * U2 + 4 * 16 * 20;
-  size_t xch = 256 * (4 * (size_t)((F + 1) / 2) + 1);      // P6 exchange scratch aliases the front of the LDS
-  if (f < xch) f = xch;
+             3 * (size_t)EX + U1 * U2 + U1 + 2 * U2 + 4 * (size_t)EX * HS;
   return f * sizeof(float);
 }
 
