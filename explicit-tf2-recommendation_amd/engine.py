@@ -258,6 +258,8 @@ class DeepFMFusedStep:
     ``self.bad_ids`` (checked by ``check_flags()``).
     """
 
+    NBUF = 6            # plan buffers (see __init__)
+
     def __init__(self, layer, batch_size, field_dims, field_offsets, optimizer=None, lr=1e-3, use_graph=True):
         self.layer = layer
         self.B = B = int(batch_size)
@@ -293,18 +295,27 @@ class DeepFMFusedStep:
             "bias": torch.empty(1, **f32),
         }
         self.ws = torch.empty(lib.rec_deepfm_fused_workspace_bytes(B, F), dtype=torch.uint8, device=dev)
-        # two plan buffers: the de-duplication plan depends on the ids only, so the plan of batch k+1 can be built
-        # (second stream) while batch k is being differentiated
-        self.plans = [dict(perm=torch.empty((F, B), dtype=torch.int32, device=dev),
-                           col_uid=torch.empty((F, B), dtype=torch.int64, device=dev),
-                           col_seg=torch.empty((F, B + 1), dtype=torch.int32, device=dev),
-                           col_nu=torch.zeros(F, dtype=torch.int32, device=dev)) for _ in range(2)]
+        # NBUF plan buffers: the de-duplication plan depends on the ids only, so the plan of batch k+1 is built (second
+        # stream) while batch k is being differentiated.  Inside a multi-step graph of fewer than NBUF steps every batch
+        # has a buffer of its own, so no sort ever has to wait for an earlier step to release one: the sort chains
+        # depend on nothing but each other and run ahead on the second stream
+        NB = self.NBUF
+        self._perm = torch.empty((NB, F, B), dtype=torch.int32, device=dev)
+        self._col_uid = torch.empty((NB, F, B), dtype=torch.int64, device=dev)
+        self._col_seg = torch.empty((NB, F, B + 1), dtype=torch.int32, device=dev)
+        self._col_nu = torch.zeros((NB, F), dtype=torch.int32, device=dev)
+        self.plans = [dict(perm=self._perm[b], col_uid=self._col_uid[b], col_seg=self._col_seg[b],
+                           col_nu=self._col_nu[b]) for b in range(NB)]
+        # consecutive buffers are contiguous, so ONE sort call can build the plans of GROUP upcoming batches as
+        # GROUP*F columns (the sort kernels are latency-bound at < 1 wave per SIMD: two batches cost ~1.2x one)
+        self.GROUP = max(1, min(2, 64 // F))
+        self.col_lo_rep = self.col_lo.repeat(self.GROUP).contiguous()
         self._plan_key, self._plan_buf = None, 0
         self.uniq_ids = torch.empty(n, dtype=torch.int64, device=dev)
         self.g_embed_rows = torch.empty((n, 16), **f32)
         self.g_w_rows = torch.empty((n, 1), **f32)
         self.n_uniq = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.sort_ws = torch.empty(lib.rec_colsort_workspace_bytes(B, F), dtype=torch.uint8, device=dev)
+        self.sort_ws = torch.empty(lib.rec_colsort_workspace_bytes(B, F * self.GROUP), dtype=torch.uint8, device=dev)
         self.side_stream = torch.cuda.Stream(device=dev)
         if optimizer is not None:
             self.state = {name: (torch.zeros(p.shape, **f32), torch.zeros(p.shape, **f32))
@@ -314,28 +325,45 @@ class DeepFMFusedStep:
         self._graphs = {}
 
     def _sort(self, cols, buf, stream):
-        F = self.F
-        arr = (C.c_void_p * F)(*[c.data_ptr() for c in cols])
-        pl = self.plans[buf]
-        check(lib.rec_colsort_plan_i64(arr, F, self.B, self.V, _p(self.col_lo), self.max_key, _p(pl["perm"]),
+        self._sort_group([cols], buf, stream)
+
+    def _sort_group(self, cols_list, first_buf, stream):
+        """Plans of len(cols_list) <= GROUP batches into the consecutive buffers first_buf, first_buf+1, ... as one
+        rec_colsort_plan_i64 call over len*F columns."""
+        k, F = len(cols_list), self.F
+        assert 1 <= k <= self.GROUP and first_buf + k <= self.NBUF
+        arr = (C.c_void_p * (k * F))(*[c.data_ptr() for cols in cols_list for c in cols])
+        pl = self.plans[first_buf]
+        check(lib.rec_colsort_plan_i64(arr, k * F, self.B, self.V, _p(self.col_lo_rep), self.max_key, _p(pl["perm"]),
                                        _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.bad_ids),
                                        _p(self.sort_ws), C.c_void_p(stream.cuda_stream)), "rec_colsort_plan_i64")
 
-    def _enqueue(self, cols, label, t, cur, have_plan, next_cols, plan_ev=None, defer_join=False):
-        """cur: plan buffer of this batch; have_plan: it was filled by the previous step; next_cols: columns of
-        the next batch, whose plan is built into the other buffer concurrently (second stream).
-
-        Stream choreography (what a captured graph records as edges):
-          * the fork point is an event recorded BEFORE the fused kernel is enqueued, and the fused kernel is enqueued
-            first: in a captured graph both branches are roots and the runtime starts them in creation order with
-            ~15 us between them -- the 35-us kernel of the critical path must go first;
-          * only the second half of the step (reduction + segment sums) needs this batch's plan.  Inside a multi-step
-            graph the previous step hands over ``plan_ev`` (recorded on the second stream behind its sort) and this step
-            waits for it between the two halves; with ``defer_join`` this step in turn returns such an event instead of
-            joining the streams at its end, so the next fused kernel starts right behind this step's second half."""
-        L = self.layer
-        F, B, V = self.F, self.B, self.V
+    def _launch_main(self, cols, label, st):
+        L, F = self.layer, self.F
         arr = (C.c_void_p * F)(*[c.data_ptr() for c in cols])
+        emb = L.embed.embeddings
+        check(lib.rec_deepfm_fused_main_f32(
+            _p(emb), emb.stride(0), self.V, arr, F, self.B, _p(L.bias), _p(L.MLP_layer1.kernel_0),
+            _p(L.MLP_layer1.bias_0), _p(L.MLP_layer1.kernel_1), _p(L.MLP_layer1.bias_1), _p(L.MLP_layer2.kernel_0),
+            _p(L.MLP_layer2.bias_0), _p(label), _p(self.gz), _p(self.vals), None, _p(self.oob), _p(self.ws), st),
+            "rec_deepfm_fused_main_f32")
+
+    def _launch_post(self, buf, st):
+        """reduction of the workgroup partials and the segment sums side by side in ONE launch"""
+        g, pl = self.g, self.plans[buf]
+        check(lib.rec_deepfm_fused_post_f32(
+            self.F, self.B, _p(self.gz), _p(self.vals), _p(g["MLP_layer1.kernel_0"]), _p(g["MLP_layer1.bias_0"]),
+            _p(g["MLP_layer1.kernel_1"]), _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]),
+            _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(self.loss), _p(self.ws), _p(pl["perm"]), _p(pl["col_uid"]),
+            _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.uniq_ids), _p(self.g_embed_rows), _p(self.g_w_rows),
+            _p(self.n_uniq), 0, st), "rec_deepfm_fused_post_f32")
+
+    def _enqueue(self, cols, label, t, cur, have_plan, next_cols):
+        """One step.  cur: plan buffer of this batch; have_plan: it was filled by the previous step; next_cols: columns
+        of the next batch, whose plan is built into buffer cur+1 concurrently (second stream).  The fork point is an
+        event recorded BEFORE the fused kernel is enqueued, and the fused kernel is enqueued first: in a captured graph
+        both branches are roots and the runtime starts them in creation order with ~15 us between them -- the kernel of
+        the critical path must go first."""
         main = torch.cuda.current_stream()
         side = self.side_stream
         forked = (not have_plan) or (next_cols is not None)
@@ -343,40 +371,19 @@ class DeepFMFusedStep:
             fork_ev = torch.cuda.Event()
             fork_ev.record(main)                                 # a sort only needs ids: nothing of this step
         st = C.c_void_p(main.cuda_stream)
-        g = self.g
-        emb = L.embed.embeddings
-        pl = self.plans[cur]
-        check(lib.rec_deepfm_fused_main_f32(
-            _p(emb), emb.stride(0), V, arr, F, B, _p(L.bias), _p(L.MLP_layer1.kernel_0), _p(L.MLP_layer1.bias_0),
-            _p(L.MLP_layer1.kernel_1), _p(L.MLP_layer1.bias_1), _p(L.MLP_layer2.kernel_0), _p(L.MLP_layer2.bias_0),
-            _p(label), _p(self.gz), _p(self.vals), None, _p(self.oob), _p(self.ws), st), "rec_deepfm_fused_main_f32")
-        out_ev = None
+        self._launch_main(cols, label, st)
         if forked:
             side.wait_event(fork_ev)
-            with torch.cuda.stream(side):
-                if not have_plan:
-                    self._sort(cols, cur, side)                  # this batch's own plan (non-pipelined call)
-                if next_cols is not None:
-                    self._sort(next_cols, 1 - cur, side)         # the next batch's plan
-                if defer_join and next_cols is not None:
-                    out_ev = torch.cuda.Event()
-                    out_ev.record(side)
             if not have_plan:
-                main.wait_stream(side)                           # this batch's plan is needed now
-        if plan_ev is not None:
-            main.wait_event(plan_ev)                             # the plan built beside the previous step
-        # reduction of the workgroup partials and the segment sums side by side in ONE launch
-        check(lib.rec_deepfm_fused_post_f32(
-            F, B, _p(self.gz), _p(self.vals), _p(g["MLP_layer1.kernel_0"]), _p(g["MLP_layer1.bias_0"]),
-            _p(g["MLP_layer1.kernel_1"]), _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]),
-            _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(self.loss), _p(self.ws), _p(pl["perm"]), _p(pl["col_uid"]),
-            _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.uniq_ids), _p(self.g_embed_rows), _p(self.g_w_rows),
-            _p(self.n_uniq), 0, st), "rec_deepfm_fused_post_f32")
+                self._sort(cols, cur, side)                      # this batch's own plan (non-pipelined call)
+                main.wait_stream(side)                           # ... is needed now
+            if next_cols is not None:
+                self._sort(next_cols, (cur + 1) % self.NBUF, side)   # the next batch's plan
+        self._launch_post(cur, st)
         if self.optimizer is not None:
             self._optimizer(t, st)
-        if forked and have_plan and out_ev is None:
-            main.wait_stream(side)                               # join: the next step may rely on the other buffer
-        return out_ev
+        if next_cols is not None:
+            main.wait_stream(side)                               # join: the next step relies on the other buffer
 
     def _optimizer(self, t, st):
         lr, b1, b2, eps = self.lr, 0.9, 0.999, 1e-7
@@ -437,7 +444,7 @@ class DeepFMFusedStep:
                 self._graphs[gkey] = ent
             ent[0].replay()
         if next_cols is not None:
-            self._plan_key, self._plan_buf = next_key, 1 - cur
+            self._plan_key, self._plan_buf = next_key, (cur + 1) % self.NBUF
         else:
             self._plan_key = None
         return self.loss
@@ -460,14 +467,50 @@ class DeepFMFusedStep:
         cur0 = self._plan_buf if have_first else 0
         gkey = ("many", tuple(keys), tuple(y.data_ptr() for _, y in seq), then_key, cur0, have_first)
 
+        n = len(seq)
+        if n + 1 > self.NBUF:
+            raise ValueError("many(): at most %d batches per call" % (self.NBUF - 1))
+        if cur0 + n + 1 > self.NBUF:                             # keep the graph's buffers consecutive: restart at 0
+            if have_first:                                       # ... after moving the prefetched plan there
+                for k in ("perm", "col_uid", "col_seg", "col_nu"):
+                    self.plans[0][k].copy_(self.plans[cur0][k])
+            cur0 = 0
+            gkey = ("many", tuple(keys), tuple(y.data_ptr() for _, y in seq), then_key, cur0, have_first)
+
         def enqueue_all():
-            cur, have, ev = cur0, have_first, None
-            for i, (cols, y) in enumerate(seq):
-                last = i + 1 == len(seq)
-                nxt = seq[i + 1][0] if not last else then_cols
-                ev = self._enqueue(cols, y, self.t, cur, have, nxt, plan_ev=ev, defer_join=not last)
-                cur, have = 1 - cur, nxt is not None
-            return cur
+            """Every batch of the graph has a plan buffer of its own, so the sorts depend on nothing but the ids: they
+            are all enqueued up front on the second stream, GROUP batches per call, and run ahead of the main chain;
+            step i waits for its plan between its two launches."""
+            main, side = torch.cuda.current_stream(), self.side_stream
+            st = C.c_void_p(main.cuda_stream)
+            start_ev = torch.cuda.Event()
+            start_ev.record(main)
+            self._launch_main(seq[0][0], seq[0][1], st)          # the critical path's first kernel goes first
+            todo = ([] if have_first else [0]) + list(range(1, n)) + ([n] if then_cols is not None else [])
+            ready = {}
+            if todo:
+                side.wait_event(start_ev)
+                gi = 0
+                while gi < len(todo):
+                    grp = [todo[gi]]                             # up to GROUP batches with consecutive buffers
+                    while len(grp) < self.GROUP and gi + len(grp) < len(todo) and todo[gi + len(grp)] == grp[-1] + 1:
+                        grp.append(todo[gi + len(grp)])
+                    gi += len(grp)
+                    cl = [seq[i][0] if i < n else then_cols for i in grp]
+                    self._sort_group(cl, cur0 + grp[0], side)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    for i in grp:
+                        ready[i] = ev
+            for i in range(n):
+                if i > 0:
+                    self._launch_main(seq[i][0], seq[i][1], st)
+                if i in ready:
+                    main.wait_event(ready[i])
+                self._launch_post(cur0 + i, st)
+            if todo:
+                main.wait_stream(side)
+            return cur0 + n
 
         ent = self._graphs.get(gkey)
         if ent is None:
