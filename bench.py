@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=CFG["batch"])
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly (no hipGraph replay)")
+    ap.add_argument("--resident", type=int, default=4, help="resident batches = steps per captured cycle (<= 8)")
     ap.add_argument("--step-graphs", action="store_true", help="one hipGraph per step instead of one per 4-step cycle")
     ap.add_argument("--generic", action="store_true", help="use the generic ~35-kernel step instead of the fused one")
     ap.add_argument("--replicas", action="store_true",
@@ -129,7 +130,7 @@ def main():
     layer = layers.DeepFMRankingLayer(feature_names=names, feature_dims=V, embedding_dims=E,
                                       mlp_dims=CFG["mlp_dims"]).cuda()
     gen = data.SyntheticGenerator(names, V, dist=args.dist, seed=rank)
-    n_batches = 4
+    n_batches = args.resident
     batches = [data.to_device(gen.batch(B)) for _ in range(n_batches)]
     sharded_mode = args.sharded or (world > 1 and not args.replicas)
     if sharded_mode:    # table rows block-partitioned over the ranks; ids / rows / row gradients by RCCL all-to-all

@@ -258,7 +258,7 @@ class DeepFMFusedStep:
     ``self.bad_ids`` (checked by ``check_flags()``).
     """
 
-    NBUF = 6            # plan buffers (see __init__)
+    NBUF = 16           # plan buffers (see __init__): two halves of 8, many() alternates between them
 
     def __init__(self, layer, batch_size, field_dims, field_offsets, optimizer=None, lr=1e-3, use_graph=True):
         self.layer = layer
@@ -468,14 +468,13 @@ class DeepFMFusedStep:
         gkey = ("many", tuple(keys), tuple(y.data_ptr() for _, y in seq), then_key, cur0, have_first)
 
         n = len(seq)
-        if n + 1 > self.NBUF:
-            raise ValueError("many(): at most %d batches per call" % (self.NBUF - 1))
-        if cur0 + n + 1 > self.NBUF:                             # keep the graph's buffers consecutive: restart at 0
-            if have_first:                                       # ... after moving the prefetched plan there
-                for k in ("perm", "col_uid", "col_seg", "col_nu"):
-                    self.plans[0][k].copy_(self.plans[cur0][k])
-            cur0 = 0
-            gkey = ("many", tuple(keys), tuple(y.data_ptr() for _, y in seq), then_key, cur0, have_first)
+        half = self.NBUF // 2
+        if n > half:
+            raise ValueError("many(): at most %d batches per call" % half)
+        # plan buffers of this call: batch 0 keeps the one it was prefetched into; batches 1..n-1 and `then` get the n
+        # consecutive buffers at the start of the OTHER half of the ring (free: the previous graph has completed)
+        base = 0 if cur0 >= half else half
+        bufs = [cur0] + [base + j for j in range(n)]
 
         def enqueue_all():
             """Every batch of the graph has a plan buffer of its own, so the sorts depend on nothing but the ids: they
@@ -495,9 +494,11 @@ class DeepFMFusedStep:
                     grp = [todo[gi]]                             # up to GROUP batches with consecutive buffers
                     while len(grp) < self.GROUP and gi + len(grp) < len(todo) and todo[gi + len(grp)] == grp[-1] + 1:
                         grp.append(todo[gi + len(grp)])
+                    if grp[0] == 0:
+                        grp = grp[:1]                            # batch 0's buffer is not next to the others
                     gi += len(grp)
                     cl = [seq[i][0] if i < n else then_cols for i in grp]
-                    self._sort_group(cl, cur0 + grp[0], side)
+                    self._sort_group(cl, bufs[grp[0]], side)
                     ev = torch.cuda.Event()
                     ev.record(side)
                     for i in grp:
@@ -507,10 +508,10 @@ class DeepFMFusedStep:
                     self._launch_main(seq[i][0], seq[i][1], st)
                 if i in ready:
                     main.wait_event(ready[i])
-                self._launch_post(cur0 + i, st)
+                self._launch_post(bufs[i], st)
             if todo:
                 main.wait_stream(side)
-            return cur0 + n
+            return bufs[n]
 
         ent = self._graphs.get(gkey)
         if ent is None:
