@@ -233,11 +233,35 @@ __global__ __launch_bounds__(256) void segsum_vec_kernel(const float4* __restric
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
   } else {
-    for (int ch = s0 / CH; ch <= (s1 - 1) / CH; ++ch) {
-      int which = s0 <= ch * CH ? 0 : 1;
-      float4 v = part[((int64_t)ch * 2 + which) * lpr + c];
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    // chunk partials in chunk order.  A run of 600k rows (DIN's padding id) has 2400 of them: eight independent chains
+    // (chunk j of every eight -> chain j) keep eight loads in flight, the chains meet in a fixed tree
+    const int chb = s0 / CH, che = (s1 - 1) / CH;
+    {
+      int which = s0 <= chb * CH ? 0 : 1;
+      acc = part[((int64_t)chb * 2 + which) * lpr + c];
     }
+    float4 a8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a8[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int ch = chb + 1;                                        // every later chunk starts inside the run: slot 0
+    for (; ch + 8 <= che + 1; ch += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float4 v = part[((int64_t)(ch + j) * 2) * lpr + c];
+        a8[j].x += v.x; a8[j].y += v.y; a8[j].z += v.z; a8[j].w += v.w;
+      }
+    }
+    for (int j = 0; ch <= che; ++ch, ++j) {
+      float4 v = part[((int64_t)ch * 2) * lpr + c];
+      a8[j].x += v.x; a8[j].y += v.y; a8[j].z += v.z; a8[j].w += v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a8[j].x += a8[j + 4].x; a8[j].y += a8[j + 4].y; a8[j].z += a8[j + 4].z; a8[j].w += a8[j + 4].w;
+    }
+    a8[0].x += a8[2].x; a8[0].y += a8[2].y; a8[0].z += a8[2].z; a8[0].w += a8[2].w;
+    a8[1].x += a8[3].x; a8[1].y += a8[3].y; a8[1].z += a8[3].z; a8[1].w += a8[3].w;
+    acc.x += a8[0].x + a8[1].x; acc.y += a8[0].y + a8[1].y; acc.z += a8[0].z + a8[1].z; acc.w += a8[0].w + a8[1].w;
   }
   out[t] = acc;
 }
