@@ -199,12 +199,20 @@ def main():
         # reference point for the cost of the exchange: the same batches through the single-GPU fused step on a full
         # table replica per rank (no collective at all), timed the same way.  NOT the reported value.
         rstep = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, optimizer=None, use_graph=not args.no_graph)
-        for i in range(nw):
-            rstep(batches[i % n_batches], next_inputs=batches[(i + 1) % n_batches])
+
+        def rrun(n):
+            i = 0
+            while (not args.no_graph) and n - i >= n_batches:
+                rstep.many(batches, then=batches[0])
+                i += n_batches
+            while i < n:
+                rstep(batches[i % n_batches], next_inputs=batches[(i + 1) % n_batches])
+                i += 1
+
+        rrun(nw)
         barrier()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            rstep(batches[i % n_batches], next_inputs=batches[(i + 1) % n_batches])
+        rrun(args.steps)
         barrier()
         rel = time.perf_counter() - t0
         if world > 1:
