@@ -104,9 +104,18 @@ __global__ __launch_bounds__(256) void din_prep_bwd_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// attention forward / backward: one workgroup (4 waves) per example, waves take time steps round-robin.
-// LDS (floats): Eff [D][H+1] | c [H] | kbuf [4][D] | red [4][D]            (+ backward: gEff [4][D][H+1] | gp [4][H])
+// attention forward / backward: one workgroup (4 waves) per example.  The time axis is cut into chunks of TC = 64 steps
+// whose key rows are gathered into LDS (KT, zero-padded); the [T,D] x [D,H] product against Eff_b and, in the backward,
+// gEff = K^T . gpre and gkeys = gpre . Eff^T run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: lane l holds
+// A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; D: col = l&15, row = 4*(l>>4) + reg).  Wave w owns rows 16w..16w+15 of
+// the chunk for everything that is per time step; all dimensions are padded to multiples of 16 with zeros in LDS, so
+// padded rows / columns contribute exact zeros.  Keys are never written to HBM in the forward.
+// LDS (floats): Eff [Dp][HS] | cvec [Hp] | KT [TC][DS] | msb [TC] | maskb [TC] | red [4][Dp]
+//               backward adds: GP [TC][HS] | gsb [TC] | gpl [Dp] | redh [4][4][Hp]
 // ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int TC = 64;
+
 struct AttnArgs {
   const float* embed; int64_t ld; int64_t V; int E; int C;
   const int64_t* series; int T;
@@ -116,78 +125,190 @@ struct AttnArgs {
   int64_t padding_index; int mask_valid;
 };
 
-__device__ __forceinline__ void load_key(const AttnArgs& a, int64_t b, int t, int lane, int D, float* kb, bool* bad) {
-  for (int d = lane; d < D; d += 64) {
-    int r = d / a.E, col = d - r * a.E;
-    int64_t id = a.series[((int64_t)b * a.T + t) * a.C + r];
-    float v = 0.f;
-    if ((uint64_t)id < (uint64_t)a.V) v = a.embed[id * a.ld + col];
-    else *bad = true;
-    kb[d] = v;
+struct AttnLds {
+  int Dp, Hp, DS, HS;
+  size_t eff, cvec, kt, msb, maskb, red, gp, gsb, gpl, redh, total;   // offsets in floats
+};
+
+__host__ __device__ inline AttnLds attn_layout(int D, int H, bool bwd) {
+  AttnLds L;
+  L.Dp = (D + 15) & ~15;
+  L.Hp = (H + 15) & ~15;
+  L.DS = L.Dp + 1;
+  L.HS = L.Hp + 1;
+  size_t o = 0;
+  L.eff = o; o += (size_t)L.Dp * L.HS;
+  L.cvec = o; o += L.Hp;
+  L.kt = o; o += (size_t)TC * L.DS;
+  L.msb = o; o += TC;
+  L.maskb = o; o += TC;
+  L.red = o; o += 4 * (size_t)L.Dp;
+  L.gp = o; if (bwd) o += (size_t)TC * L.HS;
+  L.gsb = o; if (bwd) o += TC;
+  L.gpl = o; if (bwd) o += L.Dp;
+  L.redh = o; if (bwd) o += 16 * (size_t)L.Hp;
+  L.total = o;
+  return L;
+}
+
+// Eff = Wkd + M_b (zero-padded), c_b; zero the padding columns of KT once
+__device__ __forceinline__ void attn_load_eff(const AttnArgs& a, int64_t b, int D, int H, const AttnLds& L, float* lds) {
+  float* Eff = lds + L.eff;
+  float* cvec = lds + L.cvec;
+  float* KT = lds + L.kt;
+  const int64_t NM = (int64_t)D * H + H;
+  for (int i = threadIdx.x; i < L.Dp * L.HS; i += 256) {
+    int r = i / L.HS, o = i - r * L.HS;
+    Eff[i] = (r < D && o < H) ? a.Wkd[r * H + o] + a.Mext[b * NM + (int64_t)r * H + o] : 0.f;
+  }
+  for (int o = threadIdx.x; o < L.Hp; o += 256) cvec[o] = o < H ? a.Mext[b * NM + (int64_t)D * H + o] : 0.f;
+  const int padc = L.DS - D;                               // columns D .. DS-1 of every KT row stay zero
+  for (int i = threadIdx.x; i < TC * padc; i += 256) KT[(i / padc) * L.DS + D + i % padc] = 0.f;
+}
+
+// key rows t0 .. t0+TC-1 -> KT (rows beyond T and rows of out-of-range ids: zeros), mask of every row -> maskb
+__device__ __forceinline__ void attn_gather(const AttnArgs& a, int64_t b, int t0, int D, const AttnLds& L, float* lds,
+                                            bool* bad) {
+  float* KT = lds + L.kt;
+  float* maskb = lds + L.maskb;
+  const int E = a.E, C = a.C;
+  for (int idx = threadIdx.x; idx < TC * C; idx += 256) {
+    int row = idx / C, r = idx - row * C;
+    int t = t0 + row;
+    float* dst = KT + row * L.DS + r * E;
+    const float* src = nullptr;
+    if (t < a.T) {
+      int64_t id = a.series[((int64_t)b * a.T + t) * C + r];
+      if ((uint64_t)id < (uint64_t)a.V) src = a.embed + id * a.ld;
+      else *bad = true;
+      if (r == 0) {
+        bool pad = id == a.padding_index;
+        maskb[row] = (a.mask_valid ? !pad : pad) ? 1.f : 0.f;   // reference quirk: mask = (id == padding)
+      }
+    } else if (r == 0) {
+      maskb[row] = 0.f;
+    }
+    if (src) {
+      if ((E & 3) == 0 && (a.ld & 3) == 0) {
+        for (int e = 0; e < E; e += 4) {
+          float4 v = *reinterpret_cast<const float4*>(src + e);
+          dst[e] = v.x; dst[e + 1] = v.y; dst[e + 2] = v.z; dst[e + 3] = v.w;
+        }
+      } else {
+        for (int e = 0; e < E; ++e) dst[e] = src[e];
+      }
+    } else {
+      for (int e = 0; e < E; ++e) dst[e] = 0.f;
+    }
   }
 }
 
+// pre-activation tile of this wave's 16 rows: acc[n][r] = sum_d KT[r0 + 4g + r][d] * Eff[d][16n + l15]
+template <int NT>
+__device__ __forceinline__ void attn_pre_gemm(const float* KT, const float* Eff, const AttnLds& L, int r0, int l15, int g,
+                                              f32x4 (&acc)[NT]) {
+#pragma unroll
+  for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* ap = KT + (r0 + l15) * L.DS + g;
+  const float* bp = Eff + g * L.HS + l15;
+  const int nk = L.Dp >> 2;
+  float ac = ap[0], bc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) bc[n] = bp[16 * n];
+  for (int k = 0; k + 1 < nk; ++k) {
+    float an = ap[4 * (k + 1)], bn[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bn[n] = bp[4 * (k + 1) * L.HS + 16 * n];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac, bc[n], acc[n], 0, 0, 0);
+    ac = an;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bc[n] = bn[n];
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac, bc[n], acc[n], 0, 0, 0);
+}
+
+template <int NT>
 __global__ __launch_bounds__(256) void din_attn_fwd_kernel(AttnArgs a, int D, int H, float* __restrict__ scores,
                                                            float* __restrict__ pooled, int* oob) {
   extern __shared__ float lds[];
-  const int HS = H + 1;
-  float* Eff = lds;
-  float* cvec = Eff + D * HS;
-  float* kbuf = cvec + H;
-  float* red = kbuf + 4 * D;
+  const AttnLds L = attn_layout(D, H, false);
+  float* Eff = lds + L.eff;
+  float* cvec = lds + L.cvec;
+  float* KT = lds + L.kt;
+  float* msb = lds + L.msb;
+  float* maskb = lds + L.maskb;
+  float* red = lds + L.red;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4, r0 = wave * 16;
   const int64_t b = blockIdx.x;
-  const int64_t NM = (int64_t)D * H + H;
-  for (int i = tid; i < D * H; i += 256) {
-    int r = i / H, o = i - r * H;
-    Eff[r * HS + o] = a.Wkd[i] + a.Mext[b * NM + i];
-  }
-  for (int o = tid; o < H; o += 256) cvec[o] = a.Mext[b * NM + (int64_t)D * H + o];
-  __syncthreads();
-  float* kb = kbuf + wave * D;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};   // pooled dims lane, lane+64, lane+128, lane+192
-  bool bad = false;
-  const float al = (lane < H && a.alpha) ? a.alpha[lane] : 0.f;
-  const float mu = (lane < H && a.mean) ? a.mean[lane] : 0.f;
-  const float vr = (lane < H && a.var) ? a.var[lane] : 1.f;
-  const float w2 = lane < H ? a.w2[lane] : 0.f;
-  const float b2 = a.b2[0];
-  for (int t0 = 0; t0 < a.T; t0 += 4) {
-    int t = t0 + wave;
-    bool live = t < a.T;
-    if (live) load_key(a, b, t, lane, D, kb, &bad);
-    __syncthreads();
-    if (live) {
-      float pre = 0.f;
-      if (lane < H) {
-        pre = cvec[lane];
-        for (int i = 0; i < D; ++i) pre += kb[i] * Eff[i * HS + lane];
-      }
-      float h = lane < H ? feat_act(a.act, pre, al, mu, vr, nullptr, nullptr) : 0.f;
-      float s = wave_sum64(h * w2) + b2;
-      int64_t id0 = a.series[((int64_t)b * a.T + t) * a.C];
-      bool pad = id0 == a.padding_index;
-      float m = (a.mask_valid ? !pad : pad) ? 1.f : 0.f;   // reference quirk: mask = (id == padding)
-      if (lane == 0) scores[b * a.T + t] = s;
-      float ms = m * s;
+  attn_load_eff(a, b, D, H, L, lds);
+  float al[NT], mu[NT], vr[NT], w2h[NT];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int d = lane + 64 * j;
-        if (d < D) acc[j] += ms * kb[d];
+  for (int n = 0; n < NT; ++n) {
+    int h = 16 * n + l15;
+    bool ok = h < H;
+    al[n] = (ok && a.alpha) ? a.alpha[h] : 0.f;
+    mu[n] = (ok && a.mean) ? a.mean[h] : 0.f;
+    vr[n] = (ok && a.var) ? a.var[h] : 1.f;
+    w2h[n] = ok ? a.w2[h] : 0.f;                           // padded units contribute nothing to the score
+  }
+  const float b2 = a.b2[0];
+  float pacc[4] = {0.f, 0.f, 0.f, 0.f};                    // pooled dims lane, lane+64, lane+128, lane+192
+  bool bad = false;
+  for (int t0 = 0; t0 < a.T; t0 += TC) {
+    __syncthreads();                                       // Eff ready / previous chunk consumed
+    attn_gather(a, b, t0, D, L, lds, &bad);
+    __syncthreads();
+    f32x4 acc[NT];
+    attn_pre_gemm<NT>(KT, Eff, L, r0, l15, g, acc);
+    float sr[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      float cv = cvec[16 * n + l15];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        sr[r] += feat_act(a.act, acc[n][r] + cv, al[n], mu[n], vr[n], nullptr, nullptr) * w2h[n];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) sr[r] += __shfl_xor(sr[r], o, 64);      // over the 16 unit lanes
+      sr[r] += b2;
+    }
+    if (l15 == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = r0 + 4 * g + r, t = t0 + row;
+        if (t < a.T) scores[b * a.T + t] = sr[r];
+        msb[row] = maskb[row] * sr[r];
       }
     }
-    __syncthreads();
+    // masked weighted sum of this wave's 16 key rows (msb of these rows was written by this wave)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int d = lane + 64 * j;
+      if (d < L.Dp) {
+        float p = 0.f;
+#pragma unroll
+        for (int row = 0; row < 16; ++row) p += msb[r0 + row] * KT[(r0 + row) * L.DS + d];
+        pacc[j] += p;
+      }
+    }
   }
   if (bad && oob) *oob = 1;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     int d = lane + 64 * j;
-    if (d < D) red[wave * D + d] = acc[j];
+    if (d < L.Dp) red[wave * L.Dp + d] = pacc[j];
   }
   __syncthreads();
-  for (int d = tid; d < D; d += 256) pooled[b * D + d] = red[d] + red[D + d] + red[2 * D + d] + red[3 * D + d];
+  for (int d = tid; d < D; d += 256)
+    pooled[b * D + d] = ((red[d] + red[L.Dp + d]) + red[2 * L.Dp + d]) + red[3 * L.Dp + d];
 }
 
+template <int NT>
 __global__ __launch_bounds__(256) void din_attn_bwd_kernel(AttnArgs a, int D, int H, const float* __restrict__ scores,
                                                            const float* __restrict__ gpooled,
                                                            float* __restrict__ gkeys /* [B,T,D] */,
@@ -196,101 +317,177 @@ __global__ __launch_bounds__(256) void din_attn_bwd_kernel(AttnArgs a, int D, in
                                                            float* __restrict__ galphap /* [B,H] */,
                                                            float* __restrict__ gb2p /* [B] */) {
   extern __shared__ float lds[];
-  const int HS = H + 1;
-  float* Eff = lds;
-  float* cvec = Eff + D * HS;
-  float* kbuf = cvec + H;
-  float* gpl = kbuf + 4 * D;          // g_pooled [D]
-  float* gpb = gpl + D;               // gpre per wave [4][H]
-  float* gEff = gpb + 4 * H;          // [4][D][HS]
+  const AttnLds L = attn_layout(D, H, true);
+  float* Eff = lds + L.eff;
+  float* cvec = lds + L.cvec;
+  float* KT = lds + L.kt;
+  float* msb = lds + L.msb;
+  float* maskb = lds + L.maskb;
+  float* GP = lds + L.gp;
+  float* gsb = lds + L.gsb;
+  float* gpl = lds + L.gpl;
+  float* redh = lds + L.redh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4, r0 = wave * 16;
   const int64_t b = blockIdx.x;
   const int64_t NM = (int64_t)D * H + H;
-  for (int i = tid; i < D * H; i += 256) {
-    int r = i / H, o = i - r * H;
-    Eff[r * HS + o] = a.Wkd[i] + a.Mext[b * NM + i];
+  attn_load_eff(a, b, D, H, L, lds);
+  for (int d = tid; d < L.Dp; d += 256) gpl[d] = d < D ? gpooled[b * D + d] : 0.f;
+  float al[NT], mu[NT], vr[NT], w2h[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    int h = 16 * n + l15;
+    bool ok = h < H;
+    al[n] = (ok && a.alpha) ? a.alpha[h] : 0.f;
+    mu[n] = (ok && a.mean) ? a.mean[h] : 0.f;
+    vr[n] = (ok && a.var) ? a.var[h] : 1.f;
+    w2h[n] = ok ? a.w2[h] : 0.f;
   }
-  for (int o = tid; o < H; o += 256) cvec[o] = a.Mext[b * NM + (int64_t)D * H + o];
-  for (int d = tid; d < D; d += 256) gpl[d] = gpooled[b * D + d];
-  for (int i = tid; i < 4 * D * HS; i += 256) gEff[i] = 0.f;
-  __syncthreads();
-  float* kb = kbuf + wave * D;
-  float* gp = gpb + wave * H;
-  float* gE = gEff + wave * D * HS;
+  // gEff row tiles of this wave: wave, wave + 4, ... (Dp/16 <= 16 tiles)
+  constexpr int MTW = 4;
+  const int nmt = L.Dp >> 4;
+  f32x4 ge[MTW][NT];
+#pragma unroll
+  for (int i = 0; i < MTW; ++i)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) ge[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float gc[NT], gw2a[NT], gala[NT], gb2a = 0.f;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) { gc[n] = 0.f; gw2a[n] = 0.f; gala[n] = 0.f; }
   bool bad = false;
-  const float al = (lane < H && a.alpha) ? a.alpha[lane] : 0.f;
-  const float mu = (lane < H && a.mean) ? a.mean[lane] : 0.f;
-  const float vr = (lane < H && a.var) ? a.var[lane] : 1.f;
-  const float w2 = lane < H ? a.w2[lane] : 0.f;
-  float gc = 0.f, gw2 = 0.f, gal = 0.f, gb2 = 0.f;
-  for (int t0 = 0; t0 < a.T; t0 += 4) {
-    int t = t0 + wave;
-    bool live = t < a.T;
-    if (live) load_key(a, b, t, lane, D, kb, &bad);
+  for (int t0 = 0; t0 < a.T; t0 += TC) {
     __syncthreads();
-    float m = 0.f, s = 0.f, gs = 0.f;
-    if (live) {
-      int64_t id0 = a.series[((int64_t)b * a.T + t) * a.C];
-      bool pad = id0 == a.padding_index;
-      m = (a.mask_valid ? !pad : pad) ? 1.f : 0.f;
-      s = scores[b * a.T + t];
+    attn_gather(a, b, t0, D, L, lds, &bad);
+    __syncthreads();
+    // (1) pre-activations of this wave's rows
+    f32x4 acc[NT];
+    attn_pre_gemm<NT>(KT, Eff, L, r0, l15, g, acc);
+    // (2) d L / d score of row l15 of this wave: mask * <g_pooled, k_t>; (mask*score) kept for the keys' gradient
+    {
       float dot = 0.f;
-      for (int d = lane; d < D; d += 64) dot += gpl[d] * kb[d];
-      gs = m * wave_sum64(dot);                          // d L / d score_t
-      float pre = 0.f, dydx = 0.f, dyda = 0.f, h = 0.f;
-      if (lane < H) {
-        pre = cvec[lane];
-        for (int i = 0; i < D; ++i) pre += kb[i] * Eff[i * HS + lane];
-        h = feat_act(a.act, pre, al, mu, vr, &dydx, &dyda);
-      }
-      float gh = gs * w2;
-      float gpre = gh * dydx;
-      if (lane < H) {
-        gw2 += gs * h;
-        gal += gh * dyda;
-        gc += gpre;
-        gp[lane] = gpre;
-        for (int i = 0; i < D; ++i) gE[i * HS + lane] += kb[i] * gpre;
-      }
-      if (lane == 0) gb2 += gs;
-    }
-    __syncthreads();
-    if (live) {
-      for (int d = lane; d < D; d += 64) {
-        float g = m * s * gpl[d];
-        for (int o = 0; o < H; ++o) g += Eff[d * HS + o] * gp[o];
-        gkeys[((int64_t)b * a.T + t) * D + d] = g;
+      const float* kr = KT + (r0 + l15) * L.DS + g;
+      for (int j = 0; j < (L.Dp >> 2); ++j) dot += gpl[4 * j + g] * kr[4 * j];
+      dot += __shfl_xor(dot, 16, 64);
+      dot += __shfl_xor(dot, 32, 64);
+      if (g == 0) {
+        int row = r0 + l15, t = t0 + row;
+        float m = maskb[row];
+        gsb[row] = m * dot;
+        msb[row] = t < a.T ? m * scores[b * a.T + t] : 0.f;
       }
     }
-    __syncthreads();
+    float gsr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gsr[r] = gsb[r0 + 4 * g + r];
+    // (3) through the score layer and the activation; gpre tile -> LDS
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      float cv = cvec[16 * n + l15];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float dydx, dyda;
+        float hv = feat_act(a.act, acc[n][r] + cv, al[n], mu[n], vr[n], &dydx, &dyda);
+        float gh = gsr[r] * w2h[n];
+        float gpre = gh * dydx;
+        gw2a[n] += gsr[r] * hv;
+        gala[n] += gh * dyda;
+        gc[n] += gpre;
+        GP[(r0 + 4 * g + r) * L.HS + 16 * n + l15] = gpre;
+      }
+    }
+    if (l15 == 0) gb2a += (gsr[0] + gsr[1]) + (gsr[2] + gsr[3]);
+    __syncthreads();                                       // GP of all 64 rows
+    // (4) gEff += K^T . gpre over the chunk's rows
+    {
+      const int nk = TC >> 2;
+      for (int k = 0; k < nk; ++k) {
+        float bv[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bv[n] = GP[(4 * k + g) * L.HS + 16 * n + l15];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+          int mt = wave + 4 * i;
+          if (mt < nmt) {
+            float av = KT[(4 * k + g) * L.DS + 16 * mt + l15];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) ge[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[n], ge[i][n], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // (5) gkeys of this wave's rows: mask*score*g_pooled + gpre . Eff^T
+    {
+      const int nkh = L.Hp >> 2;
+      float msr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) msr[r] = msb[r0 + 4 * g + r];
+      for (int dt = 0; dt < nmt; ++dt) {
+        f32x4 ak = {0.f, 0.f, 0.f, 0.f};
+        const float* ap = GP + (r0 + l15) * L.HS + g;
+        const float* bp = Eff + (16 * dt + l15) * L.HS + g;
+        for (int k = 0; k < nkh; ++k) ak = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * k], bp[4 * k], ak, 0, 0, 0);
+        int d = 16 * dt + l15;
+        if (d < D) {
+          float gp_d = gpl[d];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int t = t0 + r0 + 4 * g + r;
+            if (t < a.T) gkeys[((int64_t)b * a.T + t) * D + d] = msr[r] * gp_d + ak[r];
+          }
+        }
+      }
+    }
   }
-  // cross-wave reductions in a fixed order
-  for (int i = tid; i < D * H; i += 256) {
-    int r = i / H, o = i - r * H;
-    int k = r * HS + o;
-    gMext[b * NM + i] = gEff[k] + gEff[D * HS + k] + gEff[2 * D * HS + k] + gEff[3 * D * HS + k];
+  // gEff -> gMext[b, d*H + h]
+#pragma unroll
+  for (int i = 0; i < MTW; ++i) {
+    int mt = wave + 4 * i;
+    if (mt < nmt) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        int h = 16 * n + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int d = 16 * mt + 4 * g + r;
+          if (d < D && h < H) gMext[b * NM + (int64_t)d * H + h] = ge[i][n][r];
+        }
+      }
+    }
   }
+  // per-unit sums: over the row groups of the wave (lanes g), then over the waves in a fixed order
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    gc[n] += __shfl_xor(gc[n], 16, 64); gc[n] += __shfl_xor(gc[n], 32, 64);
+    gw2a[n] += __shfl_xor(gw2a[n], 16, 64); gw2a[n] += __shfl_xor(gw2a[n], 32, 64);
+    gala[n] += __shfl_xor(gala[n], 16, 64); gala[n] += __shfl_xor(gala[n], 32, 64);
+  }
+  gb2a += __shfl_xor(gb2a, 16, 64);
+  gb2a += __shfl_xor(gb2a, 32, 64);
   __syncthreads();
-  float* red = gEff;                                     // reuse: [4][4][H]
-  if (lane < H) {
-    red[(wave * 4 + 0) * H + lane] = gc;
-    red[(wave * 4 + 1) * H + lane] = gw2;
-    red[(wave * 4 + 2) * H + lane] = gal;
-    red[(wave * 4 + 3) * H + lane] = lane == 0 ? gb2 : 0.f;
+  if (g == 0) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      int h = 16 * n + l15;
+      redh[(wave * 4 + 0) * L.Hp + h] = gc[n];
+      redh[(wave * 4 + 1) * L.Hp + h] = gw2a[n];
+      redh[(wave * 4 + 2) * L.Hp + h] = gala[n];
+    }
+    if (l15 == 0) redh[(wave * 4 + 3) * L.Hp] = gb2a;
   }
   __syncthreads();
   if (tid < H) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     for (int wv = 0; wv < 4; ++wv) {
-      s0 += red[(wv * 4 + 0) * H + tid];
-      s1 += red[(wv * 4 + 1) * H + tid];
-      s2 += red[(wv * 4 + 2) * H + tid];
+      s0 += redh[(wv * 4 + 0) * L.Hp + tid];
+      s1 += redh[(wv * 4 + 1) * L.Hp + tid];
+      s2 += redh[(wv * 4 + 2) * L.Hp + tid];
     }
     gMext[b * NM + (int64_t)D * H + tid] = s0;
     gw2p[b * H + tid] = s1;
     galphap[b * H + tid] = s2;
   }
-  if (tid == 0) gb2p[b] = red[3 * H] + red[(4 + 3) * H] + red[(8 + 3) * H] + red[(12 + 3) * H];
+  if (tid == 0)
+    gb2p[b] = ((redh[3 * L.Hp] + redh[(4 + 3) * L.Hp]) + redh[(8 + 3) * L.Hp]) + redh[(12 + 3) * L.Hp];
   (void)bad;
 }
 
@@ -429,12 +626,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   for (int n = lane; n < N; n += 64) gx[row * N + n] = y[row * N + n] * (gy[row * N + n] - s);
 }
 
-size_t attn_lds_bytes(int D, int H, bool bwd) {
-  size_t f = (size_t)D * (H + 1) + H + 4 * (size_t)D;
-  if (bwd) f += (size_t)D + 4 * (size_t)H + 4 * (size_t)D * (H + 1);
-  else f += 4 * (size_t)D;
-  return f * sizeof(float);
-}
+size_t attn_lds_bytes(int D, int H, bool bwd) { return attn_layout(D, H, bwd).total * sizeof(float); }
 
 bool attn_args_ok(int D, int H, int E, int C, int T) {
   return D > 0 && H > 0 && E > 0 && C > 0 && T > 0 && D == E * C && H <= 64 && D <= 256;
@@ -473,10 +665,23 @@ extern "C" int rec_din_attn_fwd_f32(const float* embed, int64_t ld, int64_t V, i
   if (!embed || !series || !Mext || !Wkd || !w2 || !b2 || !scores || !pooled) return REC_E_ARG;
   if ((act == DACT_DICE && (!alpha || !mean || !var)) || (act == DACT_PRELU && !alpha)) return REC_E_ARG;
   size_t lds = attn_lds_bytes(D, H, false);
-  if (lds > 64 * 1024) return REC_E_UNSUPPORTED;
+  if (lds > 150 * 1024) return REC_E_UNSUPPORTED;
   AttnArgs a{embed, ld, V, E, C, series, T, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index, mask_valid};
-  hipLaunchKernelGGL(din_attn_fwd_kernel, dim3((unsigned)B), dim3(256), lds, as_stream(stream), a, D, H, scores, pooled,
-                     oob_flag);
+#define LAUNCH_FWD(NT)                                                                                            \
+  do {                                                                                                            \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_fwd_kernel<NT>),                   \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+    if (e != hipSuccess) return (int)e;                                                                           \
+    hipLaunchKernelGGL(din_attn_fwd_kernel<NT>, dim3((unsigned)B), dim3(256), lds, as_stream(stream), a, D, H,    \
+                       scores, pooled, oob_flag);                                                                 \
+  } while (0)
+  switch ((H + 15) / 16) {
+    case 1: LAUNCH_FWD(1); break;
+    case 2: LAUNCH_FWD(2); break;
+    case 3: LAUNCH_FWD(3); break;
+    default: LAUNCH_FWD(4); break;
+  }
+#undef LAUNCH_FWD
   REC_LAUNCH_CHECK();
   return REC_OK;
 }
@@ -497,13 +702,21 @@ extern "C" int rec_din_attn_bwd_f32(const float* embed, int64_t ld, int64_t V, i
   size_t lds = attn_lds_bytes(D, H, true);
   if (lds > 150 * 1024) return REC_E_UNSUPPORTED;
   AttnArgs a{embed, ld, V, E, C, series, T, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index, mask_valid};
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_bwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+#define LAUNCH_BWD(NT)                                                                                            \
+  do {                                                                                                            \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_bwd_kernel<NT>),                   \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+    if (e != hipSuccess) return (int)e;                                                                           \
+    hipLaunchKernelGGL(din_attn_bwd_kernel<NT>, dim3((unsigned)B), dim3(256), lds, as_stream(stream), a, D, H,    \
+                       scores, gpooled, gkeys, gMext, gw2p, galphap, gb2p);                                       \
+  } while (0)
+  switch ((H + 15) / 16) {
+    case 1: LAUNCH_BWD(1); break;
+    case 2: LAUNCH_BWD(2); break;
+    case 3: LAUNCH_BWD(3); break;
+    default: LAUNCH_BWD(4); break;
   }
-  hipLaunchKernelGGL(din_attn_bwd_kernel, dim3((unsigned)B), dim3(256), lds, as_stream(stream), a, D, H, scores, gpooled,
-                     gkeys, gMext, gw2p, galphap, gb2p);
+#undef LAUNCH_BWD
   REC_LAUNCH_CHECK();
   return REC_OK;
 }
