@@ -43,6 +43,9 @@ SIGNATURES = {
     "rec_adam_rows_f32": (i32, [p, i64, p, p, i64, i32, p, p, p, i64, i64, f32, f32, f32, f32, p]),
     "rec_l2_rows_workspace_bytes": (sz, [i64, i32]),
     "rec_l2_rows_f32": (i32, [p, i64, i64, i32, p, p, i64, f32, p, p, p, p]),
+    "rec_l2_normalize_rows_f32": (i32, [p, i64, i32, i64, p, i64, p]),
+    "rec_topk_l2_workspace_bytes": (sz, [i64, i64, i32]),
+    "rec_topk_l2_f32": (i32, [p, i64, i32, i64, p, i64, i64, i32, p, p, p, sz, p]),
     "rec_shard_bucketize_workspace_bytes": (sz, [i64, i32]),
     "rec_shard_bucketize_i64": (i32, [p, i64, i64, i32, p, p, p, p, p, sz, p]),
     "rec_colsort_shard_map_i64": (i32, [p, p, p, p, i64, i32, i64, i32, p, p, p, p, p, p]),

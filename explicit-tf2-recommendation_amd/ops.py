@@ -359,6 +359,35 @@ def permute_rows(x, perm, scatter):
 
 
 # ---------------------------------------------------------------------------------------------------
+# retrieval
+# ---------------------------------------------------------------------------------------------------
+def l2_normalize_rows(x):
+    """x / ||x||_2 per row (2.FM/OfflineLoader.py:140)."""
+    _table(x, "x")                                       # 2-D fp32 CUDA, unit inner stride, any row stride
+    y = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+    check(lib.rec_l2_normalize_rows_f32(_ptr(x), x.shape[0], x.shape[1], x.stride(0), _ptr(y), y.stride(0), _stream()),
+          "rec_l2_normalize_rows_f32")
+    return y
+
+
+def topk_l2(queries, items, k):
+    """BallTree(items).query(queries, k) of the reference, brute force: (dist [nq,k] ascending, ind [nq,k] int64)."""
+    _table(queries, "queries"); _table(items, "items")   # row views of wider buffers are fine
+    if queries.shape[1] != items.shape[1]:
+        raise ValueError("queries [nq,d] and items [n,d] must share d")
+    nq, d = queries.shape
+    n = items.shape[0]
+    dev = queries.device
+    ind = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    nbytes = lib.rec_topk_l2_workspace_bytes(nq, n, k)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(lib.rec_topk_l2_f32(_ptr(queries), nq, d, queries.stride(0), _ptr(items), n, items.stride(0), k, _ptr(ind),
+                              _ptr(dist), _ptr(ws), nbytes, _stream()), "rec_topk_l2_f32")
+    return dist, ind
+
+
+# ---------------------------------------------------------------------------------------------------
 # DIN
 # ---------------------------------------------------------------------------------------------------
 DACT_NONE, DACT_RELU, DACT_SIGMOID, DACT_TANH, DACT_DICE, DACT_PRELU = range(6)

@@ -183,6 +183,16 @@ size_t rec_l2_rows_workspace_bytes(int64_t n, int E);
 int rec_l2_rows_f32(const float* table, int64_t ld, int64_t V, int E, const int64_t* uniq_ids, const int64_t* n_uniq,
                     int64_t n, float factor, float* rows_out, float* loss, float* workspace, void* stream);
 
+/* ---- retrieval after the DSSM towers (2.FM/OfflineLoader.py:129-162, 2.FM/OnlineServer.py:53-75:
+ * item vectors L2-normalised, sklearn BallTree(Euclidean).query(raw user vector, k) -- an exact search, i.e. the k
+ * smallest ||u - i_hat||_2 ascending).  rec_l2_normalize_rows_f32: y[r,:] = x[r,:] / ||x[r,:]||_2.
+ * rec_topk_l2_f32: out_idx [nq,k] (int64, item row numbers; equal distances: the lower index first), out_dist [nq,k]
+ * ascending; k <= 64, d <= 64; if n < k the tail is (-1, +inf).  workspace: rec_topk_l2_workspace_bytes(nq, n, k). */
+int rec_l2_normalize_rows_f32(const float* x, int64_t n, int d, int64_t ld_in, float* y, int64_t ld_out, void* stream);
+size_t rec_topk_l2_workspace_bytes(int64_t nq, int64_t n, int k);
+int rec_topk_l2_f32(const float* queries, int64_t nq, int d, int64_t ldq, const float* items, int64_t n, int64_t ldi,
+                    int k, int64_t* out_idx, float* out_dist, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- (e) row-wise block sharding of a table (no reference counterpart).
  * owner = id / rows_per_shard.  perm[n]: positions grouped by owner, ascending inside a group;
  * send_counts[n_shard] (int64); local_ids[n] = ids[perm] - owner*rows_per_shard. */

@@ -8,6 +8,7 @@ batches, one MI355X.  Prints one JSON line per config.  Usage:  python scripts/b
   C   DCN matrix CrossNet, 10 cat + 3 cont, V=10M, E=32, L=3, B=16384 (D=323); C26 = 26 cat fields (D=835)
   D   DSSM two-tower, item V=100M x 64d on ONE GPU (25.6 GB table; the 8-way sharded form is sharded.py), B=8192
   E   DIN, T=100, V=50M, E=32, B=4096
+  R   retrieval after the towers: 10M items x 8d (L2-normalised), 1024 user vectors, top-20
 """
 import json
 import os
@@ -122,6 +123,17 @@ def run(name):
         dt = timed(fwd_bwd(layer, batch, user + item + ser), 2, 10)
         return {"config": "E DIN T=100, 50M x 32d", "B": B, "V": V, "ms_per_step": dt * 1e3, "examples_per_s": B / dt,
                 "attention_flops_factorised_fwd": 2.0 * B * 96 * 96 * 36 + 2.0 * B * T * 96 * 36}
+    if name == "R":
+        from explicit_tf2_recommendation_amd import ops
+        n, d, nq, k = 10_000_000, 8, 1024, 20
+        g = torch.Generator(device="cuda").manual_seed(0)
+        items = ops.l2_normalize_rows(torch.randn((n, d), device="cuda", generator=g))
+        q = torch.randn((nq, d), device="cuda", generator=g) * 0.5
+        dt = timed(lambda: ops.topk_l2(q, items, k), 2, 10)
+        return {"config": "R retrieval top-%d, %d items x %dd, %d queries" % (k, n, d, nq), "B": nq, "V": n,
+                "ms_per_step": dt * 1e3, "examples_per_s": nq / dt, "pairs_per_s": nq * n / dt,
+                "valu_tflops (3*d flop per pair)": 3.0 * d * nq * n / dt / 1e12,
+                "hbm_GBps (items read once per 256 queries)": n * d * 4 * ((nq + 255) // 256) / dt / 1e9}
     raise SystemExit("unknown config %r" % name)
 
 
