@@ -25,6 +25,12 @@ struct Layout {
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
+// rocPRIM's radix sort switches from merge sort to its Onesweep algorithm above 2^20 items, and a captured hipGraph
+// that contains Onesweep faults when it is REPLAYED (memory aperture violation, seen with n = 1.27M: the DIN table
+// gradient at B = 4096, T = 100).  While the stream is being captured the merge-sort path is therefore kept for every size.
+using MergeSortOnly = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                 rocprim::default_config, (size_t(1) << 40)>;
+
 Layout make_layout(int64_t n) {
   Layout L;
   size_t off = 0;
@@ -32,9 +38,12 @@ Layout make_layout(int64_t n) {
   L.keys_out = off; off = align256(off + sizeof(uint32_t) * n);
   L.pos_in = off; off = align256(off + sizeof(int32_t) * n);
   L.tile_heads = off; off = align256(off + sizeof(int32_t) * (size_t)(ceil_div64(n, TILE) + 1));
-  size_t tmp = 0;
+  size_t tmp = 0, tmp2 = 0;
   (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr,
                             (int32_t*)nullptr, (size_t)n, 0, 32, (hipStream_t)0);
+  (void)rocprim::radix_sort_pairs<MergeSortOnly>(nullptr, tmp2, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                                 (int32_t*)nullptr, (int32_t*)nullptr, (size_t)n, 0, 32, (hipStream_t)0);
+  if (tmp2 > tmp) tmp = tmp2;
   L.sort_tmp = off;
   L.sort_tmp_bytes = tmp;
   off = align256(off + tmp);
@@ -362,8 +371,14 @@ extern "C" int rec_dedup_plan_i64(const int64_t* ids, int64_t n, int64_t V, int6
   unsigned end_bit = 1;
   while (end_bit < 32 && (int64_t(1) << end_bit) < V) ++end_bit;
   size_t tmp = L.sort_tmp_bytes;
-  hipError_t e = rocprim::radix_sort_pairs(ws + L.sort_tmp, tmp, keys_in, keys_out, pos_in, perm, (size_t)n, 0u,
-                                           end_bit, st);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  hipError_t e = hipStreamIsCapturing(st, &cap);
+  if (e != hipSuccess) return (int)e;
+  if (cap == hipStreamCaptureStatusActive)
+    e = rocprim::radix_sort_pairs<MergeSortOnly>(ws + L.sort_tmp, tmp, keys_in, keys_out, pos_in, perm, (size_t)n, 0u,
+                                                 end_bit, st);
+  else
+    e = rocprim::radix_sort_pairs(ws + L.sort_tmp, tmp, keys_in, keys_out, pos_in, perm, (size_t)n, 0u, end_bit, st);
   if (e != hipSuccess) return (int)e;
   int n_tiles = (int)ceil_div64(n, TILE);
   hipLaunchKernelGGL(count_heads_kernel, dim3(n_tiles), dim3(256), 0, st, keys_out, n, tile_heads);

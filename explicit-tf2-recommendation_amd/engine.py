@@ -856,3 +856,69 @@ class ShardedDeepFMStep:
         if int(self.oob.item()) != 0:
             raise IndexError("embedding id out of range [0, feature_dims)")
         self.be.check_flags()
+
+
+class GraphedTrainStep:
+    """Any layer of layers.py under the reference's loss as ONE replayed hipGraph: forward, KerasBCE and the whole
+    autograd backward (every kernel goes through the C ABI on torch's current stream, nothing synchronises, all
+    intermediates come from the graph's private pool), for the families that have no hand-fused step (DSSM towers, DCN,
+    DIN).  The eager path costs ~0.5-1 ms of Python and launch overhead per iteration whatever the batch; a replay
+    costs one graph launch.
+
+        step = GraphedTrainStep(layer, example_batch, label_name="label")
+        loss = step(batch)            # copies the batch into the static input buffers, replays; .grad of every parameter
+                                      # is a tensor of the graph (dense, or sparse COO rows for tables) valid until the
+                                      # next replay
+
+    The debug-mode bounds check of the layers (one host read per call) is switched off on this layer's modules: a host
+    read cannot be captured.  Out-of-range ids then read as zero rows, as the kernels guarantee (no fault).
+    """
+
+    def __init__(self, layer, example_batch, label_name="label", loss_fn=None, warmup=3):
+        from . import functional as Fn
+        from . import layers as CL
+        self.layer = layer
+        self.label_name = label_name
+        self.static = {k: v.clone() for k, v in example_batch.items() if isinstance(v, torch.Tensor)}
+        self.loss_fn = loss_fn or (lambda out, y: Fn.KerasBCE.apply(out, y))
+        for m in layer.modules():
+            if isinstance(m, CL.Layer):
+                m.check_ids = False                          # a host read of the bounds flag cannot be captured
+        self.params = [p for p in layer.parameters() if p.requires_grad]
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._fwd_bwd()
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        for p in self.params:
+            p.grad = None
+        with torch.cuda.graph(self.graph):
+            self.loss = self._fwd_bwd()
+        self.grads = [p.grad for p in self.params]           # tensors of the graph's pool: refreshed by every replay
+
+    def _target(self, out):
+        y = self.static[self.label_name].to(torch.float32)
+        if out.dim() == 2 and out.shape[1] > 1 and y.reshape(-1).numel() == out.shape[0]:
+            y = y.reshape(-1, 1).expand(-1, out.shape[1])
+        return y.contiguous()
+
+    def _fwd_bwd(self):
+        for p in self.params:
+            p.grad = None
+        ins = {k: v for k, v in self.static.items() if k != self.label_name}
+        out = self.layer(ins)["output"]
+        loss = self.loss_fn(out, self._target(out))
+        loss.backward()
+        return loss.detach()
+
+    def __call__(self, batch):
+        for k, v in self.static.items():
+            v.copy_(batch[k], non_blocking=True)
+        self.graph.replay()
+        for p, g in zip(self.params, self.grads):
+            p.grad = g
+        return self.loss

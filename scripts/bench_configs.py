@@ -35,7 +35,15 @@ def timed(fn, warmup, iters):
     return (time.perf_counter() - t0) / iters
 
 
+GRAPHED = False      # --graphed: engine.GraphedTrainStep (forward + loss + autograd backward as one replayed hipGraph)
+
+
 def fwd_bwd(layer, batch, names_all):
+    if GRAPHED:
+        from explicit_tf2_recommendation_amd import engine
+        b = {k: batch[k] for k in list(names_all) + ["label"]}
+        gstep = engine.GraphedTrainStep(layer, b)
+        return lambda: gstep(b)
     ins = {k: batch[k] for k in names_all}
 
     def step():
@@ -138,7 +146,11 @@ def run(name):
 
 
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or ["A", "B", "C", "C26", "D", "E"]):
+    argv = [a for a in sys.argv[1:] if a != "--graphed"]
+    GRAPHED = "--graphed" in sys.argv[1:]
+    for n in (argv or ["A", "B", "C", "C26", "D", "E", "R"]):
         r = run(n)
+        if GRAPHED and n in ("B", "C", "C26", "D", "E"):
+            r["config"] += " [GraphedTrainStep]"
         r["n_gpus"] = 1
         print(json.dumps(r), flush=True)

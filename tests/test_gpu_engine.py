@@ -299,3 +299,52 @@ def test_fused_step_with_keras_adam_matches_generic():
         b(batch)
     for (k, p), (_, q) in zip(la.named_parameters(), lb.named_parameters()):
         assert np.abs(p.detach().cpu().numpy() - q.detach().cpu().numpy()).max() <= 2e-5, k
+
+
+@pytest.mark.parametrize("family", ["dssm", "dcn_matrix", "dcn_vec", "din"])
+def test_graphed_train_step_equals_eager_autograd(family):
+    """engine.GraphedTrainStep: forward + KerasBCE + autograd backward replayed from one hipGraph must give the eager
+    path's loss and gradients on every batch it is fed (static input buffers, gradients in the graph's pool)."""
+    import copy
+    from explicit_tf2_recommendation_amd import engine, data, layers, functional as Fn
+    B, V = 192, 4000
+    layers.set_init_seed(41)
+    if family == "dssm":
+        un, inn = ["user_tag1", "user_tag2"], ["item_tag1", "item_tag2", "item_tag3"]
+        layer = layers.DSSMTwoTowerRetrievalLayer(u_feature_names=un, i_feature_names=inn, u_feature_dims=V,
+                                                  i_feature_dims=V).cuda()
+        gen = data.SyntheticGenerator(un + inn, V, dist="zipf", seed=1)
+    elif family.startswith("dcn"):
+        cat, cont = ["c%d" % i for i in range(6)], ["x0", "x1"]
+        layer = layers.DeepCrossNetworkLayer(categorical_features=cat, continuous_features=cont, feature_dims=V,
+                                             embedding_dims=8, layer_num=2,
+                                             type="matrix" if family == "dcn_matrix" else "vec").cuda()
+        gen = data.SyntheticGenerator(cat, V, continuous=cont, dist="zipf", seed=2)
+    else:
+        user, item = ["uid", "utag1"], ["i_goods_id", "i_shop_id", "i_cate_id"]
+        ser = ["visited_goods_ids", "visited_shop_ids", "visited_cate_ids"]
+        layer = layers.DINLayer(user_and_context_categorical_features=user, item_categorical_features=item,
+                                behavior_series_features=ser, feature_dims=V, embedding_dims=8).cuda()
+        gen = data.SyntheticGenerator(user + item, V, series=ser, seq_len=9, seed=3)
+    batches = [data.to_device(gen.batch(B)) for _ in range(3)]
+    eager = copy.deepcopy(layer)
+    step = engine.GraphedTrainStep(layer, batches[0])
+
+    def eager_grads(b):
+        for p in eager.parameters():
+            p.grad = None
+        out = eager({k: v for k, v in b.items() if k != "label"})["output"]
+        y = b["label"]
+        if out.dim() == 2 and out.shape[1] > 1:
+            y = y.expand(-1, out.shape[1]).contiguous()
+        loss = Fn.KerasBCE.apply(out, y)
+        loss.backward()
+        return loss.item(), [p.grad.to_dense().clone() if p.grad.is_sparse else p.grad.clone() for p in eager.parameters()]
+
+    for b in (batches[1], batches[2], batches[0], batches[1]):
+        loss = step(b).item()
+        want_loss, want = eager_grads(b)
+        assert abs(loss - want_loss) <= 1e-6 * max(1.0, abs(want_loss))
+        for (name, p), w in zip(layer.named_parameters(), want):
+            g = p.grad.to_dense() if p.grad.is_sparse else p.grad
+            assert torch.equal(g, w), name                  # same kernels in the same order: bit identical
