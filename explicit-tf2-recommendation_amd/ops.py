@@ -247,12 +247,14 @@ def copy_cols(src, dst_view):
 
 
 def split_k_for(K, M, N):
-    """Heuristic split of a reduction over the batch so that ~>=256 workgroups run."""
+    """Heuristic split of a reduction over the batch so that ~768 workgroups run.  The 64x64 kernel spends ~2 us per
+    16-deep k step (no prefetch), so a few-tile weight gradient [M,N] = X^T dY with K = batch is cut down to 64-deep
+    slices (M=192, N=64, K=8192: 41 -> ~10 us); the partials are added in slice order by the split-K reduce."""
     t = 128 if (M > 64 and N > 64) else 64          # tile edge the kernel will use
     tiles = ((M + t - 1) // t) * ((N + t - 1) // t)
     if tiles >= 512 or K < 1024:
         return 1
-    return int(max(1, min(64, -(-768 // max(tiles, 1)), K // 256)))
+    return int(max(1, min(256, -(-768 // max(tiles, 1)), K // 64)))
 
 
 # ---------------------------------------------------------------------------------------------------
