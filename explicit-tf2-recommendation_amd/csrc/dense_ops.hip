@@ -76,13 +76,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
   }
 }
 
+// second stage: 32 columns x 8 row slices per workgroup (slice r adds partials r, r+8, ...), slices combined in order
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nrb, int64_t N,
                                                            float* __restrict__ out) {
-  int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (col >= N) return;
-  float s = 0.f;
-  for (int q = 0; q < nrb; ++q) s += part[(int64_t)q * N + col];
-  out[col] = s;
+  __shared__ float sh[8][33];
+  int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+  int64_t col = (int64_t)blockIdx.x * 32 + c;
+  float acc = 0.f;
+  if (col < N) {
+#pragma unroll 4
+    for (int q = r; q < nrb; q += 8) acc += part[(int64_t)q * N + col];
+  }
+  sh[r][c] = acc;
+  __syncthreads();
+  if (r == 0 && col < N) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += sh[q][c];
+    out[col] = s;
+  }
 }
 
 __global__ __launch_bounds__(256) void axpby_kernel(float a, const float* __restrict__ x, float b,
@@ -529,7 +541,7 @@ extern "C" int rec_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx,
                      rpb, nrb > 1 ? workspace : out);
   REC_LAUNCH_CHECK();
   if (nrb > 1) {
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div64(N, 256)), dim3(256), 0, st, workspace, nrb, N,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div64(N, 32)), dim3(256), 0, st, workspace, nrb, N,
                        out);
     REC_LAUNCH_CHECK();
   }

@@ -196,8 +196,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= M * N) return;
   int64_t gm = t / N, gn = t - gm * N;
-  float acc = 0.f;
-  for (int z = 0; z < split; ++z) acc += ws[(int64_t)z * M * N + t];  // fixed order
+  // fixed order: four chains (slice z -> chain z mod 4) keep several loads in flight, then one fixed tree
+  const int64_t MN = M * N;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int z = 0;
+  for (; z + 4 <= split; z += 4) {
+    a0 += ws[(int64_t)z * MN + t];
+    a1 += ws[(int64_t)(z + 1) * MN + t];
+    a2 += ws[(int64_t)(z + 2) * MN + t];
+    a3 += ws[(int64_t)(z + 3) * MN + t];
+  }
+  if (z < split) a0 += ws[(int64_t)z * MN + t];
+  if (z + 1 < split) a1 += ws[(int64_t)(z + 1) * MN + t];
+  if (z + 2 < split) a2 += ws[(int64_t)(z + 2) * MN + t];
+  float acc = (a0 + a1) + (a2 + a3);
   C[gm * ldc + gn] = epilogue(epi, acc, gm, gn, bias, e0, lde0, e1, lde1, aux, ldc);
 }
 

@@ -254,7 +254,9 @@ def split_k_for(K, M, N):
     tiles = ((M + t - 1) // t) * ((N + t - 1) // t)
     if tiles >= 512 or K < 1024:
         return 1
-    return int(max(1, min(256, -(-768 // max(tiles, 1)), K // 64)))
+    split = max(1, min(256, -(-768 // max(tiles, 1)), K // 64))
+    cap = max(8, (16 << 20) // max(1, 4 * M * N))       # the partials are written and read again: at most 16 MB of them
+    return int(min(split, cap))
 
 
 # ---------------------------------------------------------------------------------------------------
