@@ -213,6 +213,14 @@ class ModelManager:
         self._metric_update(scaled_loss.item(), target, logits["output"])
         return scaled_loss
 
+    def init_dataset(self, mode="train", data_dir=None, feature_names=None, label_name=None):
+        """2.FM/ModelManager.py:122-153: the TFRecord files of ``data_dir`` whose name contains ``mode``, parsed as
+        FixedLenFeature([1]) and batched (tfrecord.TFRecordDataset; no TensorFlow involved)."""
+        from . import tfrecord
+        assert mode in ("train", "test")
+        self.set_feature_names(feature_names, label_name)
+        return tfrecord.TFRecordDataset(data_dir, mode, self.feature_names, self.label_name, self.batch)
+
     def train_step(self, ds, epoch=None, summary_writer=None):
         self._metric_reset()
         step = 0
