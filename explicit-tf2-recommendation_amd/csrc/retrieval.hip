@@ -22,7 +22,7 @@
 
 namespace {
 
-constexpr int STEP = 64;       // items per wave step (one per lane)
+constexpr int STEP = 128;      // items per wave pass (two steps of one item per lane)
 
 __global__ __launch_bounds__(256) void l2_normalize_rows_kernel(const float* __restrict__ x, int64_t n, int d, int64_t ld_in,
                                                                 float* __restrict__ y, int64_t ld_out) {
@@ -58,56 +58,70 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(const float* __restrict_
   const int64_t ss = ((int64_t)blockIdx.x * 4 + wave) * sub;         // this wave's sub-slab [ss, se)
   const int64_t se = ss + sub < n ? ss + sub : n;
   float thr = FLT_MAX;                                               // lane q: K-th best distance^2 of query q so far
-  for (int64_t t0 = ss; t0 < se; t0 += 64) {
-    const int64_t it = t0 + lane;
-    const bool have = it < se;
-    float x[D];
+  // the rare survivor of the threshold test: the whole wave puts (v, idx) into query qq's ascending list.  Everything
+  // after the two LDS reads stays in the vector unit: v_readlane for the broadcasts, a DPP wave shift for "take your
+  // left neighbour's element" (an LDS-routed shuffle would add a round trip each)
+  auto insert = [&](int qq, float v, int idx) {
+    float* row = lv + qq * K;
+    int* rowi = li + qq * K;
+    float ev = lane < K ? row[lane] : FLT_MAX;                       // lanes 0..K-1 hold the list; K <= 64
+    int ei = lane < K ? rowi[lane] : -1;
+    const float last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ev), K - 1));
+    if (!(v < last)) return;                                         // an earlier survivor of this step raised the bar
+    const int pos = __popcll(__ballot(lane < K && !(v < ev)));       // elements <= v stay in front: ties keep the earlier
+    const float pv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ev), 0x138, 0xf, 0xf, false));
+    const int pi = __builtin_amdgcn_update_dpp(0, ei, 0x138, 0xf, 0xf, false);                 // wave_shr:1
+    const float nv = lane < pos ? ev : (lane == pos ? v : pv);
+    if (lane < K) {
+      row[lane] = nv;
+      rowi[lane] = lane < pos ? ei : (lane == pos ? idx : pi);
+    }
+    const float nthr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nv), K - 1));
+    if (lane == qq) thr = nthr;
+  };
+  // two steps of 64 items per pass (one item per lane and step, vectors in registers), queries four at a time: their
+  // vectors are the same for every lane (broadcast LDS reads, issued together and used for 128 pairs each); the
+  // threshold of query q sits in lane q of `thr` and is read with v_readlane (q is wave-uniform)
+  for (int64_t t0 = ss; t0 < se; t0 += 128) {
+    bool have[2];
+    float x[2][D];
 #pragma unroll
-    for (int j = 0; j < D; ++j) x[j] = (have && j < d) ? items[it * ldi + j] : 0.f;
-    // queries four at a time: their vectors are the same for every lane (broadcast LDS reads, issued together), the
-    // threshold of query q sits in lane q of `thr` and is read with v_readlane (q is wave-uniform)
+    for (int sb = 0; sb < 2; ++sb) {
+      const int64_t it = t0 + 64 * sb + lane;
+      have[sb] = it < se;
+#pragma unroll
+      for (int j = 0; j < D; ++j) x[sb][j] = (have[sb] && j < d) ? items[it * ldi + j] : 0.f;
+    }
 #pragma unroll 1
     for (int qq0 = 0; qq0 < QW; qq0 += 4) {
-      float acc[4];
+      float acc[4][2];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float* qv = qs + (qq0 + u) * D;
-        float a0 = 0.f;
+        float a0 = 0.f, a1 = 0.f;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-          float df = qv[j] - x[j];
-          a0 += df * df;
+          const float qj = qv[j];
+          const float d0 = qj - x[0][j], d1 = qj - x[1][j];
+          a0 += d0 * d0;
+          a1 += d1 * d1;
         }
-        acc[u] = a0;
+        acc[u][0] = a0;
+        acc[u][1] = a1;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int qq = qq0 + u;
-        const float tq = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(thr), qq));
-        unsigned long long m = __ballot(have && acc[u] < tq);
-        while (m) {                                                  // rare; survivors in lane (= index) order
-          const int src = __ffsll((long long)m) - 1;
-          m &= m - 1;
-          const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc[u]), src));
-          const int idx = (int)(t0 - ss) + src;
-          float* row = lv + qq * K;
-          int* rowi = li + qq * K;
-          float ev = lane < K ? row[lane] : FLT_MAX;                 // lanes 0..K-1 hold the list; K <= 64
-          int ei = lane < K ? rowi[lane] : -1;
-          // everything after the two LDS reads stays in the vector unit: v_readlane for the broadcasts, a DPP wave
-          // shift for "take your left neighbour's element" (an LDS-routed shuffle would add a round trip each)
-          const float last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ev), K - 1));
-          if (!(v < last)) continue;                                 // an earlier survivor of this step raised the bar
-          const int pos = __popcll(__ballot(lane < K && !(v < ev))); // elements <= v stay in front: ties keep the earlier
-          const float pv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ev), 0x138, 0xf, 0xf, false));
-          const int pi = __builtin_amdgcn_update_dpp(0, ei, 0x138, 0xf, 0xf, false);          // wave_shr:1
-          const float nv = lane < pos ? ev : (lane == pos ? v : pv);
-          if (lane < K) {
-            row[lane] = nv;
-            rowi[lane] = lane < pos ? ei : (lane == pos ? idx : pi);
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {                             // step 0's items come before step 1's: index order
+          const float tq = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(thr), qq));
+          unsigned long long m = __ballot(have[sb] && acc[u][sb] < tq);
+          while (m) {                                                // rare; survivors in lane (= index) order
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            insert(qq, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc[u][sb]), src)),
+                   (int)(t0 - ss) + 64 * sb + src);
           }
-          const float nthr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nv), K - 1));
-          if (lane == qq) thr = nthr;
         }
       }
     }
