@@ -313,7 +313,7 @@ def main():
         roofline = roof("deepfm_fwd_bwd_kernel (gather, FM, MLP on fp32 MFMA, BCE, backward, IndexedSlices values; its "
                         "workgroup partials are reduced in the next launch)", fused_bytes, timed(launch_fused, 50),
                         ["deepfm_fwd_bwd_kernel"],
-                        "latency/sync-bound at one 122-KB workgroup per CU; 0.65 GFLOP of fp32 MFMA per launch is ~1% of "
+                        "latency/sync-bound at one 134-KB workgroup per CU; 0.65 GFLOP of fp32 MFMA per launch is ~1% of "
                         "the matrix peak, so HBM is the binding roofline")
 
     extra = {}

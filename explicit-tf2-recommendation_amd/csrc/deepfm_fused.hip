@@ -2,22 +2,27 @@
 // default head (embedding_dims = 16, mlp_dims = [32, 8]) on the fused [embed(16) | w | pad] 128-byte row layout.
 //
 // The generic path runs ~35 launch-bound kernels per step (profiles/r01_v1_*): at batch 8192 every small kernel costs
-// ~5 us while the whole gather is ~4 us of HBM time.  Here a step is FOUR launches:
+// ~5 us while the whole gather is ~4 us of HBM time.  Here a step is two launches on the main stream plus the sort of an
+// upcoming batch's ids on a second one:
 //
 //   deepfm_fwd_bwd_kernel   one workgroup (4 waves) per 32 examples: index assembly straight from the F feature
 //                           columns, gather of the 128-B rows (26 independent 16-B loads in flight per lane), FM,
-//                           MLP 416->32 on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, operands from LDS), the two
-//                           small layers + sigmoid + Keras BCE + their backward on the VALU, dX = dpre1 . K0^T and the
-//                           per-workgroup dK0 partial on the matrix cores, and the IndexedSlices values
-//                           dz*(S - e) + dX written once.  The embedding rows never leave LDS.
-//   deepfm_reduce_kernel    fixed-order sum of the per-workgroup partials (dK0, dK1, biases, loss).
+//                           MLP 416->32 on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, operands from LDS, K split
+//                           over the waves), the two small layers + sigmoid + Keras BCE + their backward on the VALU,
+//                           dX = dpre1 . K0^T and the per-workgroup dK0 partial on the matrix cores (one 32-wide tile
+//                           per wave at a time), and the IndexedSlices values dz*(S - e) + dX written once as full
+//                           128-byte lines.  The embedding rows never leave LDS.
+//   deepfm_post_kernel      ONE launch, two jobs side by side: the fixed-order sum of the per-workgroup partials (dK0,
+//                           dK1, biases, loss) and the segment sums of embed and w gradients over the batch's
+//                           de-duplication plan + global compaction (column counts prefix).  (deepfm_reduce_kernel
+//                           and colseg_sum_kernel are the same two jobs as separate launches.)
 //   colsort_*_kernel (3)    de-duplication plan: the DataGenerator contract (2.FM/DataGenerator.py:76-88) gives every
 //                           feature column its own contiguous id range, so duplicates only occur inside a column:
 //                           each column (B <= 16384 ids) is sorted on its own as 32-bit (key << PB | position) words
 //                           -- 1024-id chunks by a bitonic network (registers / wave shuffles / LDS), chunks merged
-//                           by ranking (binary searches in LDS), then run detection.  Independent of the kernel
-//                           above: the engine runs it on a second stream.
-//   colseg_sum_kernel       segment sums of embed and w gradients + global compaction (column counts prefix).
+//                           by ranking (binary searches in LDS), then run detection, all on a (B/1024) x columns
+//                           grid.  Depends on ids only: the engine runs it ahead, on a second stream, for up to two
+//                           upcoming batches per call.
 //
 // Everything is deterministic (no float atomics): per-workgroup partials + fixed-order reductions, stable sort keys.
 #include "common.h"
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(256) void deepfm_fwd_bwd_kernel(Cols cols, FusedArg
   float* DP1 = H1s + EX * HS;            // [EX][HS]      d pre-activation of layer 1
   float* Ss = DP1 + EX * HS;             // [EX][16]
   // ids (P0-P1) and the first-order weights Wl (P1-P2) are dead before H1s / DP1 are first written (P3, P4):
-  // they share that region (2*EX*F <= 2*EX*HS for F <= 33), which keeps the workgroup at ~122 KB of LDS so that a
+  // they share that region (2*EX*F <= 2*EX*HS for F <= 33), which keeps the workgroup at ~134 KB of LDS so that a
   // 32-KB sort workgroup of the second stream can be co-resident on the CU
   float* Wl = H1s;                       // [EX*F]
   int* ids = reinterpret_cast<int*>(H1s + EX * F);   // [EX*F]
@@ -560,7 +565,7 @@ __global__ __launch_bounds__(256) void colsort_chunk_kernel(Cols cols, const int
 
 __global__ __launch_bounds__(256) void colsort_rank_kernel(ColSortArgs a) {
   // the other chunks of the column pass through LDS one at a time (two 4-KB buffers, one barrier per chunk): 8 KB
-  // of LDS, so these workgroups fit next to the 122-KB workgroups of the fused kernel on a CU
+  // of LDS, so these workgroups fit next to the 134-KB workgroups of the fused kernel on a CU
   __shared__ uint32_t buf[2][CHK];
   const int tid = threadIdx.x;
   const int ch = blockIdx.x, f = blockIdx.y;

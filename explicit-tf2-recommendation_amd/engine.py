@@ -248,9 +248,10 @@ def _bits(n):
 
 
 class DeepFMFusedStep:
-    """The same train_loop iteration as DeepFMTrainStep in FOUR launches (csrc/deepfm_fused.hip): the fused
-    forward+backward kernel and its fixed-order reduction on one stream, the per-column LDS sort of the
-    de-duplication plan on a second stream (it depends only on the ids), then the segment sums.
+    """The same train_loop iteration as DeepFMTrainStep in two launches on the main stream (csrc/deepfm_fused.hip):
+    the fused forward+backward kernel, then ONE launch for the fixed-order reduction of its partials and the segment
+    sums -- plus the per-column LDS sort of the de-duplication plan of upcoming batches on a second stream (it depends
+    only on the ids).  ``many()`` runs several iterations as one captured hipGraph.
 
     Requirements (checked; otherwise use DeepFMTrainStep): embedding_dims 16, mlp_dims [32,8], fused table layout,
     F <= 28, B <= 16384, and the DataGenerator id-space contract -- ``field_offsets[f]``/``field_dims[f]`` =
