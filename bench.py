@@ -39,7 +39,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=CFG["batch"])
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly (no hipGraph replay)")
-    ap.add_argument("--resident", type=int, default=4, help="resident batches = steps per captured cycle (<= 8)")
+    ap.add_argument("--resident", type=int, default=16,
+                    help="distinct batches resident in HBM and cycled through (16 x 27 MB of table rows > the 256 MB "
+                         "memory-side cache: no step finds its rows cached from the previous cycle)")
+    ap.add_argument("--cycle", type=int, default=4, help="steps per captured hipGraph (<= 8; must divide --resident)")
     ap.add_argument("--step-graphs", action="store_true", help="one hipGraph per step instead of one per 4-step cycle")
     ap.add_argument("--generic", action="store_true", help="use the generic ~35-kernel step instead of the fused one")
     ap.add_argument("--replicas", action="store_true",
@@ -131,6 +134,9 @@ def main():
                                       mlp_dims=CFG["mlp_dims"]).cuda()
     gen = data.SyntheticGenerator(names, V, dist=args.dist, seed=rank)
     n_batches = args.resident
+    Cy = args.cycle
+    if n_batches % Cy or Cy > 8:
+        raise SystemExit("--cycle must divide --resident and be <= 8")
     batches = [data.to_device(gen.batch(B)) for _ in range(n_batches)]
     sharded_mode = args.sharded or (world > 1 and not args.replicas)
     if sharded_mode:    # table rows block-partitioned over the ranks; ids / rows / row gradients by RCCL all-to-all
@@ -155,18 +161,20 @@ def main():
         else:   # the next batch is announced: its de-duplication plan is built while this one is differentiated
             step(batches[i % n_batches], next_inputs=batches[(i + 1) % n_batches])
 
-    # launch-bound inner loop: the n_batches resident batches are replayed as ONE captured hipGraph of n_batches steps
-    # (one graph launch costs ~20 us of idle GPU); --step-graphs keeps one graph per step
+    # launch-bound inner loop: the resident batches are cycled through --cycle steps per captured hipGraph (one graph
+    # launch costs ~20 us of idle GPU); --step-graphs keeps one graph per step
     cycle = (not sharded_mode) and (not args.generic) and (not args.no_graph) and (not args.step_graphs)
 
     def run_steps(n):
         i = 0
         if cycle:
-            while n - i >= n_batches:
-                step.many(batches, then=batches[0])
-                i += n_batches
+            while n - i >= Cy:
+                b0 = i % n_batches
+                step.many(batches[b0:b0 + Cy], then=batches[(b0 + Cy) % n_batches])
+                i += Cy
             if n - i > 0:                                        # ragged tail: one shorter graph
-                step.many(batches[:n - i], then=batches[(n - i) % n_batches])
+                b0 = i % n_batches
+                step.many(batches[b0:b0 + n - i], then=batches[(b0 + n - i) % n_batches])
                 i = n
         while i < n:
             run(i)
@@ -226,9 +234,10 @@ def main():
 
         def rrun(n):
             i = 0
-            while (not args.no_graph) and n - i >= n_batches:
-                rstep.many(batches, then=batches[0])
-                i += n_batches
+            while (not args.no_graph) and n - i >= Cy:
+                b0 = i % n_batches
+                rstep.many(batches[b0:b0 + Cy], then=batches[(b0 + Cy) % n_batches])
+                i += Cy
             while i < n:
                 rstep(batches[i % n_batches], next_inputs=batches[(i + 1) % n_batches])
                 i += 1
@@ -286,37 +295,41 @@ def main():
 
     # (1) standalone gather + FM forward (what FMRankingLayer's forward launches): ids + embed rows + w + logit
     gather_bytes = B * F * (8 + E * 4 + 4) + B * 4
-    X = ops.index_pack([batches[0][k] for k in names])
+    # every launch of the timed replay takes another resident batch: no launch finds its rows in the memory-side cache
+    Xs = [ops.index_pack([b[k] for k in names]) for b in batches]
     emb, w, bias = layer.embed.embeddings, layer.w.embeddings, layer.bias
     zbuf = torch.empty(B, dtype=torch.float32, device="cuda")
 
     def launch_gather(n):
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        for _ in range(n):
-            check(lib.rec_emb_fm_fwd_f32(vp(emb), emb.stride(0), vp(w), w.stride(0), vp(bias), V, E, vp(X), B, F,
-                                         vp(zbuf), None, None, None, None, st), "rec_emb_fm_fwd_f32")
+        for i in range(n):
+            check(lib.rec_emb_fm_fwd_f32(vp(emb), emb.stride(0), vp(w), w.stride(0), vp(bias), V, E,
+                                         vp(Xs[i % n_batches]), B, F, vp(zbuf), None, None, None, None, st),
+                  "rec_emb_fm_fwd_f32")
 
     roofline_gather = roof("emb_fm_fwd_vec_kernel<8,2,fused> (embedding gather + FM, fused 128-B rows)", gather_bytes,
                            timed(launch_gather, 100), ["emb_fm_fwd_vec_kernel"],
-                           "a random row read costs one 128-B line whatever the row size (~50 G lines/s measured): "
-                           "the ceiling of this kernel is ~0.47 of the 8 TB/s spec in algorithmic bytes")
+                           "a random row read costs one 128-B line whatever the row size; measured WITHOUT cache "
+                           "reuse (scripts/exp/gather_bench3.hip: fresh ids every launch) the chip sustains ~31 G lines/s "
+                           "= 3.9 TB/s, so the ceiling of this kernel is ~0.29 of the 8 TB/s spec in algorithmic bytes; "
+                           "every timed launch here takes another resident batch (no reuse through L2 / the 256-MB "
+                           "memory-side cache)")
     roofline = roofline_gather
     if not args.generic:
         # (2) the dominant kernel of the timed step: the fused forward+backward kernel.  Algorithmic bytes: the gather
         # above + labels + dL/dz + the IndexedSlices values it writes.
         fused_bytes = gather_bytes + B * 4 + B * 4 + B * F * E * 4
         fs = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, optimizer=None, use_graph=False)
-        cols = [batches[0][k] for k in names]
-        arr = (C.c_void_p * F)(*[c.data_ptr() for c in cols])
+        arrs = [(C.c_void_p * F)(*[b[k].data_ptr() for k in names]) for b in batches]
         L, g = layer, fs.g
 
         def launch_fused(n):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            for _ in range(n):
+            for i in range(n):
                 check(lib.rec_deepfm_fused_main_f32(
-                    vp(emb), emb.stride(0), V, arr, F, B, vp(L.bias), vp(L.MLP_layer1.kernel_0),
+                    vp(emb), emb.stride(0), V, arrs[i % n_batches], F, B, vp(L.bias), vp(L.MLP_layer1.kernel_0),
                     vp(L.MLP_layer1.bias_0), vp(L.MLP_layer1.kernel_1), vp(L.MLP_layer1.bias_1),
-                    vp(L.MLP_layer2.kernel_0), vp(L.MLP_layer2.bias_0), vp(batches[0]["label"]), vp(fs.gz),
+                    vp(L.MLP_layer2.kernel_0), vp(L.MLP_layer2.bias_0), vp(batches[i % n_batches]["label"]), vp(fs.gz),
                     vp(fs.vals), None, vp(fs.oob), vp(fs.ws), st), "rec_deepfm_fused_main_f32")
 
         roofline = roof("deepfm_fwd_bwd_kernel (gather, FM, MLP on fp32 MFMA, BCE, backward, IndexedSlices values; its "
@@ -354,7 +367,7 @@ def main():
                           ("1 process per GPU, independent full-table replicas" if world > 1 else "single GPU"),
                           "global_batch": world * B,
                           "hipgraph": ((not args.no_graph) and not sharded_mode) and
-                          ("one graph per %d-step cycle of resident batches" % n_batches if cycle else "one per step"),
+                          ("one graph per %d steps, %d resident batches" % (Cy, n_batches) if cycle else "one per step"),
                           "step": "sharded, de-duplicate first: per-column sort plan (next batch, second stream), all-to-all "
                           "of unique ids, owner gather, all-to-all of rows, fused fwd+bwd on them, per-id sums, all-to-all "
                           "of row gradients, owner rank-merge" if sharded_mode else
