@@ -738,3 +738,108 @@ extern "C" int rec_l2_rows_f32(const float* table, int64_t ld, int64_t V, int E,
   REC_LAUNCH_CHECK();
   return REC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// tf.keras.layers.BatchNormalization on [B,N] (axis=-1, non-fused path: biased batch variance for both the
+// normalisation and the moving average), as NFM applies it to [bi-interaction | continuous]
+// (3.DCN/CustomLayers.py:466,504) and MLPLayer(is_batch_norm=True) after BiasAdd (2.FM/CustomLayers.py:78-79).
+// N is a layer width (tens), B the batch: one workgroup per column, two passes for the moments like tf.nn.moments
+// (mean first, then mean of squared differences), deterministic tree sums.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();                                          // red[] may still be read from the previous call
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) s += red[w];
+  return s;
+}
+
+__global__ __launch_bounds__(1024) void batchnorm_fwd_kernel(const float* __restrict__ x, int64_t ld_x, int64_t B, int N,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, float momentum,
+                                                             int training, float* __restrict__ moving_mean,
+                                                             float* __restrict__ moving_var, float* __restrict__ y,
+                                                             float* __restrict__ xhat, float* __restrict__ rstd_out) {
+  __shared__ float red[16];
+  const int n = blockIdx.x;
+  float mean, var;
+  if (training) {
+    float s = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += 1024) s += x[b * ld_x + n];
+    mean = block_sum_1024(s, red) / (float)B;
+    float q = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += 1024) {
+      float d = x[b * ld_x + n] - mean;
+      q += d * d;
+    }
+    var = block_sum_1024(q, red) / (float)B;
+    if (threadIdx.x == 0) {
+      moving_mean[n] = moving_mean[n] * momentum + mean * (1.f - momentum);
+      moving_var[n] = moving_var[n] * momentum + var * (1.f - momentum);
+    }
+  } else {
+    mean = moving_mean[n];
+    var = moving_var[n];
+  }
+  const float rstd = 1.0f / sqrtf(var + eps);
+  const float ga = gamma ? gamma[n] : 1.f, be = beta ? beta[n] : 0.f;
+  if (threadIdx.x == 0 && rstd_out) rstd_out[n] = rstd;
+  for (int64_t b = threadIdx.x; b < B; b += 1024) {
+    float h = (x[b * ld_x + n] - mean) * rstd;
+    if (xhat) xhat[b * N + n] = h;
+    y[b * N + n] = h * ga + be;
+  }
+}
+
+// training: gx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat));  inference: gx = gamma*rstd*g
+__global__ __launch_bounds__(1024) void batchnorm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ xhat,
+                                                             const float* __restrict__ rstd, int64_t B, int N,
+                                                             const float* __restrict__ gamma, int training,
+                                                             float* __restrict__ gx, float* __restrict__ ggamma,
+                                                             float* __restrict__ gbeta) {
+  __shared__ float red[16];
+  const int n = blockIdx.x;
+  float s = 0.f, sh = 0.f;
+  for (int64_t b = threadIdx.x; b < B; b += 1024) {
+    float gv = g[b * N + n];
+    s += gv;
+    sh += gv * xhat[b * N + n];
+  }
+  s = block_sum_1024(s, red);
+  sh = block_sum_1024(sh, red);
+  if (threadIdx.x == 0) {
+    if (gbeta) gbeta[n] = s;
+    if (ggamma) ggamma[n] = sh;
+  }
+  const float k = (gamma ? gamma[n] : 1.f) * rstd[n];
+  const float ms = training ? s / (float)B : 0.f, msh = training ? sh / (float)B : 0.f;
+  for (int64_t b = threadIdx.x; b < B; b += 1024) gx[b * N + n] = k * (g[b * N + n] - ms - xhat[b * N + n] * msh);
+}
+
+extern "C" int rec_batchnorm_fwd_f32(const float* x, int64_t ld_x, int64_t B, int N, const float* gamma,
+                                     const float* beta, float eps, float momentum, int training, float* moving_mean,
+                                     float* moving_var, float* y, float* xhat, float* rstd, void* stream) {
+  if (B < 0 || N <= 0 || ld_x < N) return REC_E_ARG;
+  if (B == 0) return REC_OK;
+  if (!x || !moving_mean || !moving_var || !y) return REC_E_ARG;
+  hipLaunchKernelGGL(batchnorm_fwd_kernel, dim3((unsigned)N), dim3(1024), 0, as_stream(stream), x, ld_x, B, N, gamma,
+                     beta, eps, momentum, training, moving_mean, moving_var, y, xhat, rstd);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_batchnorm_bwd_f32(const float* g, const float* xhat, const float* rstd, int64_t B, int N,
+                                     const float* gamma, int training, float* gx, float* ggamma, float* gbeta,
+                                     void* stream) {
+  if (B < 0 || N <= 0) return REC_E_ARG;
+  if (B == 0) return REC_OK;
+  if (!g || !xhat || !rstd || !gx) return REC_E_ARG;
+  hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3((unsigned)N), dim3(1024), 0, as_stream(stream), g, xhat, rstd, B, N,
+                     gamma, training, gx, ggamma, gbeta);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}

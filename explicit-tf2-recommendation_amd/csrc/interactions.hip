@@ -1,0 +1,430 @@
+// Sibling interaction layers that share the embedding gather:
+//   PNN inner product      2.FM/CustomLayers.py:729-745 (PNNLayer.call), :755-792 (SharedFieldsInteraction, IpnLayer)
+//   NFM bi-interaction     3.DCN/CustomLayers.py:493-503
+//   SIM GSU inner-product attention + sum pooling   7.SIM/CustomLayers.py:88-96
+// Each is the gather of embedding.hip with a different epilogue, so each is ONE kernel forward (ids -> rows -> the
+// layer's output, nothing materialised in between) and ONE kernel backward that produces the per-lookup gradient rows
+// (IndexedSlices values); de-duplication is the shared plan + segment sum of dedup.hip.  All HBM-bound on the random
+// row reads; none of them is GEMM-shaped at these sizes (F*(F-1)/2 dot products of length E per example).
+#include "common.h"
+
+// (i<j) -> position in the row-major upper triangle, the order tf.boolean_mask walks (2.FM/CustomLayers.py:768-771)
+__device__ __forceinline__ int pair_index(int i, int j, int F) { return i * F - (i * (i + 1)) / 2 + (j - i - 1); }
+
+// ------------------------------------------------------------------------------------------------
+// PNN inner product.  out[b, f*E + d] = table[X[b,f], d];  out[b, F*E + p(i,j)] = <e_i, e_j>.
+// A workgroup takes EX examples: ids -> LDS, rows -> LDS (row stride E+1: lanes that walk different rows hit
+// different banks), then every output element is one lane's job and is written coalesced.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void emb_ipn_fwd_kernel(const float* __restrict__ table, int64_t V, int E,
+                                                          int64_t ld, const int64_t* __restrict__ X, int64_t B, int F,
+                                                          int EX, int vec4, float* __restrict__ out, int64_t ld_out, int* oob) {
+  extern __shared__ float ipn_lds[];
+  const int ES = E + 1, P = F * (F - 1) / 2, W = F * E + P;
+  float* rows = ipn_lds;                                    // [EX][F][ES]
+  int* ids = reinterpret_cast<int*>(rows + EX * F * ES);    // [EX][F]
+  unsigned char* pi = reinterpret_cast<unsigned char*>(ids + EX * F);   // [P]
+  unsigned char* pj = pi + P;                                            // [P]
+  const int tid = threadIdx.x;
+  const int64_t b0 = (int64_t)blockIdx.x * EX;
+  const int n_ex = (B - b0 < EX) ? (int)(B - b0) : EX;
+  bool bad = false;
+  for (int i = tid; i < n_ex * F; i += 256) {
+    int64_t id = X[b0 * F + i];
+    bool ok = (uint64_t)id < (uint64_t)V;
+    bad |= !ok;
+    ids[i] = ok ? (int)id : -1;
+  }
+  if (bad && oob) *oob = 1;
+  for (int i = tid; i < F - 1; i += 256) {
+    int p = pair_index(i, i + 1, F);
+    for (int j = i + 1; j < F; ++j, ++p) { pi[p] = (unsigned char)i; pj[p] = (unsigned char)j; }
+  }
+  __syncthreads();
+  if (vec4) {
+    const int E4 = E >> 2;
+    for (int i = tid; i < n_ex * F * E4; i += 256) {
+      int r = i / E4, d4 = i - r * E4;
+      int id = ids[r];
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (id >= 0) v = *reinterpret_cast<const float4*>(table + (int64_t)id * ld + 4 * d4);
+      float* dst = rows + r * ES + 4 * d4;
+      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+  } else {
+    for (int i = tid; i < n_ex * F * E; i += 256) {
+      int r = i / E, d = i - r * E;
+      int id = ids[r];
+      rows[r * ES + d] = (id >= 0) ? table[(int64_t)id * ld + d] : 0.f;
+    }
+  }
+  __syncthreads();
+  for (int ex = 0; ex < n_ex; ++ex) {
+    const float* re = rows + ex * F * ES;
+    float* o = out + (b0 + ex) * ld_out;
+    for (int k = tid; k < W; k += 256) {
+      float v;
+      if (k < F * E) {
+        int f = k / E;
+        v = re[k + f];                                      // f*ES + d  with  k = f*E + d
+      } else {
+        int p = k - F * E;
+        const float* a = re + (int)pi[p] * ES;
+        const float* c = re + (int)pj[p] * ES;
+        v = 0.f;
+        for (int d = 0; d < E; ++d) v += a[d] * c[d];
+      }
+      o[k] = v;
+    }
+  }
+}
+
+// vals[b*F + i, d] = g[b, i*E + d] + sum_{j != i} g[b, F*E + p(i,j)] * e_j[d];  e is read back from the forward output
+__global__ __launch_bounds__(256) void emb_ipn_bwd_kernel(const float* __restrict__ out, int64_t ld_out,
+                                                          const float* __restrict__ g, int64_t ld_g, int64_t B, int F,
+                                                          int E, int EX, float* __restrict__ vals) {
+  extern __shared__ float ipn_lds[];
+  const int ES = E + 1, P = F * (F - 1) / 2, FE = F * E;
+  float* rows = ipn_lds;                 // [EX][F][ES]
+  float* gp = rows + EX * F * ES;        // [EX][P]
+  const int tid = threadIdx.x;
+  const int64_t b0 = (int64_t)blockIdx.x * EX;
+  const int n_ex = (B - b0 < EX) ? (int)(B - b0) : EX;
+  for (int ex = 0; ex < n_ex; ++ex) {
+    const float* o = out + (b0 + ex) * ld_out;
+    const float* gg = g + (b0 + ex) * ld_g;
+    for (int k = tid; k < FE; k += 256) rows[ex * F * ES + k + k / E] = o[k];
+    for (int p = tid; p < P; p += 256) gp[ex * P + p] = gg[FE + p];
+  }
+  __syncthreads();
+  for (int ex = 0; ex < n_ex; ++ex) {
+    const float* re = rows + ex * F * ES;
+    const float* gpe = gp + ex * P;
+    const float* gg = g + (b0 + ex) * ld_g;
+    float* vo = vals + (b0 + ex) * (int64_t)FE;
+    for (int k = tid; k < FE; k += 256) {
+      int i = k / E, d = k - i * E;
+      float acc = gg[k];
+      for (int j = 0; j < i; ++j) acc += gpe[pair_index(j, i, F)] * re[j * ES + d];
+      int p = pair_index(i, i + 1, F);
+      for (int j = i + 1; j < F; ++j, ++p) acc += gpe[p] * re[j * ES + d];
+      vo[k] = acc;
+    }
+  }
+}
+
+static int ipn_examples_per_group(int64_t B, int F, int E, bool bwd, size_t* lds) {
+  const int P = F * (F - 1) / 2;
+  int EX = 8;
+  while (EX > 1 && (B / EX) < 1024) EX >>= 1;              // >= 4 workgroups per CU before examples are grouped
+  for (;; EX >>= 1) {
+    size_t bytes = bwd ? (size_t)EX * ((size_t)F * (E + 1) + P) * 4
+                       : (size_t)EX * F * (E + 1) * 4 + (size_t)EX * F * 4 + 2 * (size_t)P + 16;
+    if (bytes <= 64 * 1024 || EX == 1) {
+      *lds = bytes;
+      return (bytes <= 64 * 1024) ? EX : 0;
+    }
+  }
+}
+
+extern "C" int rec_emb_ipn_fwd_f32(const float* table, int64_t V, int E, int64_t ld, const int64_t* X, int64_t B, int F,
+                                   float* out, int64_t ld_out, int* oob_flag, void* stream) {
+  if (V <= 0 || V > INT32_MAX || E <= 0 || ld < E || B < 0 || F <= 0 || F > 255) return REC_E_ARG;
+  if (ld_out < (int64_t)F * E + (int64_t)F * (F - 1) / 2) return REC_E_ARG;
+  if (B == 0) return REC_OK;
+  if (!table || !X || !out) return REC_E_ARG;
+  const int vec4 = (E & 3) == 0 && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(table) & 15) == 0;
+  size_t lds;
+  int EX = ipn_examples_per_group(B, F, E, false, &lds);
+  if (!EX) return REC_E_ARG;
+  hipLaunchKernelGGL(emb_ipn_fwd_kernel, dim3((unsigned)ceil_div64(B, EX)), dim3(256), lds, as_stream(stream), table, V,
+                     E, ld, X, B, F, EX, vec4, out, ld_out, oob_flag);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_emb_ipn_bwd_vals_f32(const float* out, int64_t ld_out, const float* g, int64_t ld_g, int64_t B, int F,
+                                        int E, float* vals, void* stream) {
+  if (E <= 0 || B < 0 || F <= 0 || F > 255) return REC_E_ARG;
+  const int64_t W = (int64_t)F * E + (int64_t)F * (F - 1) / 2;
+  if (ld_out < W || ld_g < W) return REC_E_ARG;
+  if (B == 0) return REC_OK;
+  if (!out || !g || !vals) return REC_E_ARG;
+  size_t lds;
+  int EX = ipn_examples_per_group(B, F, E, true, &lds);
+  if (!EX) return REC_E_ARG;
+  hipLaunchKernelGGL(emb_ipn_bwd_kernel, dim3((unsigned)ceil_div64(B, EX)), dim3(256), lds, as_stream(stream), out,
+                     ld_out, g, ld_g, B, F, E, EX, vals);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// NFM bi-interaction pooling.  out[b, d] = 0.5 * ((sum_f e_fd)^2 - sum_f e_fd^2), S[b,d] = sum_f e_fd kept for the
+// backward: vals[b*F + f, d] = g[b,d] * (S[b,d] - e_fd).  One lane per (example, 4 dims); the F row loads of a lane
+// are independent and issued 8 at a time.
+// ------------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void emb_bi_fwd_kernel(const float* __restrict__ table, int64_t V, int E, int64_t ld,
+                                                         const int64_t* __restrict__ X, int64_t B, int F,
+                                                         float* __restrict__ out, int64_t ld_out,
+                                                         float* __restrict__ sumvec, int* oob) {
+  constexpr int W = VEC ? 4 : 1;
+  const int EL = E / W;                                    // lanes per example
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= B * EL) return;
+  int64_t b = t / EL;
+  int c = (int)(t - b * EL);
+  const int64_t* ids = X + b * F;
+  float S[W], Q[W];
+#pragma unroll
+  for (int a = 0; a < W; ++a) S[a] = Q[a] = 0.f;
+  bool bad = false;
+  for (int f0 = 0; f0 < F; f0 += 8) {
+    float e[8][W];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+#pragma unroll
+      for (int a = 0; a < W; ++a) e[u][a] = 0.f;
+      if (f0 + u < F) {
+        int64_t id = ids[f0 + u];
+        if ((uint64_t)id < (uint64_t)V) {
+          if constexpr (VEC) {
+            float4 v = *reinterpret_cast<const float4*>(table + id * ld + 4 * c);
+            e[u][0] = v.x; e[u][1] = v.y; e[u][2] = v.z; e[u][3] = v.w;
+          } else {
+            e[u][0] = table[id * ld + c];
+          }
+        } else {
+          bad = true;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int a = 0; a < W; ++a) { S[a] += e[u][a]; Q[a] += e[u][a] * e[u][a]; }
+  }
+  if (bad && oob) *oob = 1;
+#pragma unroll
+  for (int a = 0; a < W; ++a) {
+    out[b * ld_out + c * W + a] = 0.5f * (S[a] * S[a] - Q[a]);
+    sumvec[b * E + c * W + a] = S[a];
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void emb_bi_bwd_kernel(const float* __restrict__ table, int64_t V, int E, int64_t ld,
+                                                         const int64_t* __restrict__ X, int64_t B, int F,
+                                                         const float* __restrict__ g, int64_t ld_g,
+                                                         const float* __restrict__ sumvec, float* __restrict__ vals) {
+  constexpr int W = VEC ? 4 : 1;
+  const int EL = E / W;
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= B * F * EL) return;
+  int64_t r = t / EL;                                      // lookup b*F + f
+  int c = (int)(t - r * EL);
+  int64_t b = r / F;
+  int64_t id = X[r];
+  bool ok = (uint64_t)id < (uint64_t)V;
+  if constexpr (VEC) {
+    float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) e = *reinterpret_cast<const float4*>(table + id * ld + 4 * c);
+    float4 S = *reinterpret_cast<const float4*>(sumvec + b * E + 4 * c);
+    const float* gg = g + b * ld_g + 4 * c;
+    float4 o = make_float4(gg[0] * (S.x - e.x), gg[1] * (S.y - e.y), gg[2] * (S.z - e.z), gg[3] * (S.w - e.w));
+    *reinterpret_cast<float4*>(vals + r * E + 4 * c) = o;
+  } else {
+    float e = ok ? table[id * ld + c] : 0.f;
+    vals[r * E + c] = g[b * ld_g + c] * (sumvec[b * E + c] - e);
+  }
+}
+
+extern "C" int rec_emb_bi_fwd_f32(const float* table, int64_t V, int E, int64_t ld, const int64_t* X, int64_t B, int F,
+                                  float* out, int64_t ld_out, float* sumvec, int* oob_flag, void* stream) {
+  if (V <= 0 || E <= 0 || ld < E || B < 0 || F <= 0 || ld_out < E) return REC_E_ARG;
+  if (B == 0) return REC_OK;
+  if (!table || !X || !out || !sumvec) return REC_E_ARG;
+  const bool vec = (E & 3) == 0 && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(table) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL((emb_bi_fwd_kernel<true>), dim3((unsigned)ceil_div64(B * (E / 4), 256)), dim3(256), 0,
+                       as_stream(stream), table, V, E, ld, X, B, F, out, ld_out, sumvec, oob_flag);
+  else
+    hipLaunchKernelGGL((emb_bi_fwd_kernel<false>), dim3((unsigned)ceil_div64(B * E, 256)), dim3(256), 0,
+                       as_stream(stream), table, V, E, ld, X, B, F, out, ld_out, sumvec, oob_flag);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_emb_bi_bwd_vals_f32(const float* table, int64_t V, int E, int64_t ld, const int64_t* X, int64_t B,
+                                       int F, const float* g, int64_t ld_g, const float* sumvec, float* vals,
+                                       void* stream) {
+  if (V <= 0 || E <= 0 || ld < E || B < 0 || F <= 0 || ld_g < E) return REC_E_ARG;
+  if (B == 0) return REC_OK;
+  if (!table || !X || !g || !sumvec || !vals) return REC_E_ARG;
+  const bool vec = (E & 3) == 0 && (ld & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(sumvec) |
+                     reinterpret_cast<uintptr_t>(vals)) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL((emb_bi_bwd_kernel<true>), dim3((unsigned)ceil_div64(B * F * (E / 4), 256)), dim3(256), 0,
+                       as_stream(stream), table, V, E, ld, X, B, F, g, ld_g, sumvec, vals);
+  else
+    hipLaunchKernelGGL((emb_bi_bwd_kernel<false>), dim3((unsigned)ceil_div64(B * F * E, 256)), dim3(256), 0,
+                       as_stream(stream), table, V, E, ld, X, B, F, g, ld_g, sumvec, vals);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SIM GSU inner-product attention.  key k_t = concat_r embed[series[b,t,r]] (D = C*E), valid[b,t] = series[b,t,0] !=
+// padding_index;  scores[b,t] = valid * <q_b, k_t>;  pooled[b,:] = sum_t scores[b,t] * k_t.
+// One wave per example, lane l owns dims l, l+64, ...; TB time steps are in flight together; padded steps are never
+// read (their score and their gradient are zero by definition).
+// backward: gs_t = <gpooled, k_t>;  gq = sum_t valid*gs_t*k_t;  gkeys[b,t,:] = scores_t*gpooled + valid*gs_t*q.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int NPL, bool BWD>
+__global__ __launch_bounds__(256) void ip_attn_kernel(const float* __restrict__ embed, int64_t ld, int64_t V, int E,
+                                                      int C, const int64_t* __restrict__ series, int64_t B, int T,
+                                                      const float* __restrict__ q, int64_t ld_q, int64_t padding_index,
+                                                      float* __restrict__ scores, float* __restrict__ pooled,
+                                                      int64_t ld_p, const float* __restrict__ gpooled, int64_t ld_gp,
+                                                      float* __restrict__ gkeys, float* __restrict__ gq, int* oob) {
+  constexpr int TB = 8;
+  extern __shared__ int attn_ids[];                        // [4 waves][T*C]; -1 = out of range, -2 = padded step
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+  const int D = C * E;
+  int* ids = attn_ids + wave * T * C;
+  bool bad = false;
+  for (int i = lane; i < T * C && b < B; i += 64) {
+    int t = i / C;
+    int64_t id = series[(b * T) * C + i];
+    int64_t id0 = series[(b * T + t) * C];
+    bool ok = (uint64_t)id < (uint64_t)V;
+    bad |= !ok;
+    ids[i] = (id0 == padding_index) ? -2 : (ok ? (int)id : -1);
+  }
+  if (bad && oob) *oob = 1;
+  __syncthreads();
+  if (b >= B) return;                                      // after the only barrier
+  int rr[NPL], ee[NPL];
+  float qv[NPL], gp[NPL], acc[NPL];
+#pragma unroll
+  for (int a = 0; a < NPL; ++a) {
+    int d = lane + 64 * a;
+    bool in = d < D;
+    rr[a] = in ? d / E : 0;
+    ee[a] = in ? d - rr[a] * E : 0;
+    qv[a] = in ? q[b * ld_q + d] : 0.f;
+    gp[a] = (BWD && in) ? gpooled[b * ld_gp + d] : 0.f;
+    acc[a] = 0.f;
+  }
+  for (int t0 = 0; t0 < T; t0 += TB) {
+    float k[TB][NPL];
+    bool valid[TB];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) {
+      int t = t0 + u;
+      valid[u] = false;
+#pragma unroll
+      for (int a = 0; a < NPL; ++a) {
+        k[u][a] = 0.f;
+        if (t < T && lane + 64 * a < D) {
+          int id = ids[t * C + rr[a]];
+          valid[u] = id != -2;
+          if (id >= 0) k[u][a] = embed[(int64_t)id * ld + ee[a]];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TB; ++u) {
+      int t = t0 + u;
+      if (t >= T) break;
+      // valid[] is lane-uniform except for lanes beyond D; take lane 0's view
+      bool m = __shfl((int)valid[u], 0, 64) != 0;
+      float part = 0.f;
+#pragma unroll
+      for (int a = 0; a < NPL; ++a) part += (BWD ? gp[a] : qv[a]) * k[u][a];
+      float dot = m ? wave_sum64(part) : 0.f;
+      if (!BWD) {
+        if (lane == 0) scores[b * T + t] = dot;
+#pragma unroll
+        for (int a = 0; a < NPL; ++a) acc[a] += dot * k[u][a];
+      } else {
+        float s = scores[b * T + t];
+#pragma unroll
+        for (int a = 0; a < NPL; ++a) {
+          acc[a] += dot * k[u][a];
+          if (lane + 64 * a < D) gkeys[(b * T + t) * D + lane + 64 * a] = s * gp[a] + dot * qv[a];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NPL; ++a) {
+    int d = lane + 64 * a;
+    if (d < D) {
+      if (!BWD) pooled[b * ld_p + d] = acc[a];
+      else gq[b * D + d] = acc[a];
+    }
+  }
+}
+
+#define IP_ATTN_LAUNCH(NPL, BWD)                                                                                   \
+  hipLaunchKernelGGL((ip_attn_kernel<NPL, BWD>), dim3((unsigned)ceil_div64(B, 4)), dim3(256), lds, as_stream(stream), \
+                     embed, ld, V, E, C, series, B, T, q, ld_q, padding_index, scores, pooled, ld_p, gpooled, ld_gp,   \
+                     gkeys, gq, oob_flag)
+
+static int ip_attn_launch(bool bwd, const float* embed, int64_t ld, int64_t V, int E, int C, const int64_t* series,
+                          int64_t B, int T, const float* q, int64_t ld_q, int64_t padding_index, float* scores,
+                          float* pooled, int64_t ld_p, const float* gpooled, int64_t ld_gp, float* gkeys, float* gq,
+                          int* oob_flag, void* stream) {
+  const int D = C * E;
+  if (V <= 0 || V > INT32_MAX || E <= 0 || C <= 0 || ld < E || B < 0 || T <= 0 || D > 256 || ld_q < D)
+    return REC_E_ARG;
+  const size_t lds = (size_t)4 * T * C * 4;
+  if (lds > 64 * 1024) return REC_E_ARG;
+  if (B == 0) return REC_OK;
+  if (!embed || !series || !q || !scores) return REC_E_ARG;
+  const int npl = (D + 63) / 64;
+  if (!bwd) {
+    switch (npl) {
+      case 1: IP_ATTN_LAUNCH(1, false); break;
+      case 2: IP_ATTN_LAUNCH(2, false); break;
+      case 3: IP_ATTN_LAUNCH(3, false); break;
+      default: IP_ATTN_LAUNCH(4, false); break;
+    }
+  } else {
+    switch (npl) {
+      case 1: IP_ATTN_LAUNCH(1, true); break;
+      case 2: IP_ATTN_LAUNCH(2, true); break;
+      case 3: IP_ATTN_LAUNCH(3, true); break;
+      default: IP_ATTN_LAUNCH(4, true); break;
+    }
+  }
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_ip_attn_fwd_f32(const float* embed, int64_t ld, int64_t V, int E, int C, const int64_t* series,
+                                   int64_t B, int T, const float* q, int64_t ld_q, int64_t padding_index, float* scores,
+                                   float* pooled, int64_t ld_pooled, int* oob_flag, void* stream) {
+  if (B > 0 && (!pooled || ld_pooled < (int64_t)C * E)) return REC_E_ARG;
+  return ip_attn_launch(false, embed, ld, V, E, C, series, B, T, q, ld_q, padding_index, scores, pooled, ld_pooled,
+                        nullptr, 0, nullptr, nullptr, oob_flag, stream);
+}
+
+extern "C" int rec_ip_attn_bwd_f32(const float* embed, int64_t ld, int64_t V, int E, int C, const int64_t* series,
+                                   int64_t B, int T, const float* q, int64_t ld_q, int64_t padding_index,
+                                   const float* scores, const float* gpooled, int64_t ld_gpooled, float* gkeys,
+                                   float* gq, void* stream) {
+  if (B > 0 && (!gpooled || !gkeys || !gq || ld_gpooled < (int64_t)C * E)) return REC_E_ARG;
+  return ip_attn_launch(true, embed, ld, V, E, C, series, B, T, q, ld_q, padding_index, const_cast<float*>(scores),
+                        nullptr, 0, gpooled, ld_gpooled, gkeys, gq, nullptr, stream);
+}

@@ -322,3 +322,90 @@ class DinAttention(torch.autograd.Function):
         plan = ops.DedupPlan(series, V)
         gembed = _sparse_grad(plan, gkeys.reshape(-1, E), E, (V, E))
         return gembed, gq, None, gW1, gb1, None, galpha, None, None, gW2, gb2, None, None, None
+
+
+class EmbIpn(torch.autograd.Function):
+    """PNN inner-product front end, fused with the lookup: X [B,F] -> [Flatten(embed(X)) | <e_i,e_j>, i<j]
+    (2.FM/CustomLayers.py:737-745 with IpnLayer :773-792).  Backward: IndexedSlices values from the saved output."""
+
+    @staticmethod
+    def forward(ctx, table, X, oob):
+        out = ops.emb_ipn_fwd(table, X, oob)
+        ctx.save_for_backward(X, out)
+        ctx.shape = tuple(table.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        X, out = ctx.saved_tensors
+        V, E = ctx.shape
+        vals = ops.emb_ipn_bwd_vals(out, g.contiguous(), X.shape[1], E)
+        plan = ops.DedupPlan(X, V)
+        return _sparse_grad(plan, vals, E, (V, E)), None, None
+
+
+class EmbBiInteraction(torch.autograd.Function):
+    """NFM bi-interaction pooling fused with the lookup, written into the leading columns of
+    [second_order | X_cont] (3.DCN/CustomLayers.py:493-503): returns that combined matrix."""
+
+    @staticmethod
+    def forward(ctx, table, X, cont, oob):
+        V, E = table.shape
+        B = X.shape[0]
+        nc = 0 if cont is None else cont.shape[1]
+        comb = torch.empty((B, E + nc), dtype=torch.float32, device=table.device)
+        _, S = ops.emb_bi_fwd(table, X, comb, oob)
+        if nc:
+            comb[:, E:] = cont
+        ctx.save_for_backward(table, X, S)
+        ctx.nc = nc
+        return comb
+
+    @staticmethod
+    def backward(ctx, g):
+        table, X, S = ctx.saved_tensors
+        V, E = table.shape
+        g = g.contiguous()
+        vals = ops.emb_bi_bwd_vals(table, X, g, S)
+        plan = ops.DedupPlan(X, V)
+        gcont = g[:, E:].contiguous() if ctx.nc and ctx.needs_input_grad[2] else None
+        return _sparse_grad(plan, vals, E, (V, E)), None, gcont, None
+
+
+class IpAttention(torch.autograd.Function):
+    """GSU inner-product attention + sum pooling over the embedded behaviour series, fused with the series lookup
+    (7.SIM/CustomLayers.py:88-96,107-118).  Returns pooled [B,D] and the masked scores [B,T]."""
+
+    @staticmethod
+    def forward(ctx, embed, q, series, padding_index, oob):
+        q = q.contiguous()
+        scores, pooled = ops.ip_attn_fwd(embed, series, q, padding_index, oob)
+        ctx.save_for_backward(embed, q, series, scores)
+        ctx.padding_index = padding_index
+        ctx.mark_non_differentiable(scores)
+        return pooled, scores
+
+    @staticmethod
+    def backward(ctx, gpooled, _gscores):
+        embed, q, series, scores = ctx.saved_tensors
+        V, E = embed.shape
+        gkeys, gq = ops.ip_attn_bwd(embed, series, q, ctx.padding_index, scores, gpooled.contiguous())
+        plan = ops.DedupPlan(series, V)
+        return _sparse_grad(plan, gkeys.reshape(-1, E), E, (V, E)), gq, None, None, None
+
+
+class BatchNorm(torch.autograd.Function):
+    """tf.keras.layers.BatchNormalization on [B,N] (training: batch statistics, moving averages updated in place)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, training, eps, momentum):
+        y, xhat, rstd = ops.batchnorm_fwd(x.contiguous(), gamma, beta, moving_mean, moving_var, training, eps, momentum)
+        ctx.save_for_backward(xhat, rstd, gamma)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        xhat, rstd, gamma = ctx.saved_tensors
+        gx, ggamma, gbeta = ops.batchnorm_bwd(g.contiguous(), xhat, rstd, gamma, ctx.training)
+        return gx, ggamma, gbeta, None, None, None, None, None

@@ -155,8 +155,7 @@ class MLPLayer(Layer):
         self.units = [units] if not isinstance(units, list) else units
         if len(self.units) <= 0:
             raise ValueError("Received an invalid value for `units`, expected a positive integer, got %r." % (units,))
-        if is_batch_norm:
-            raise NotImplementedError("is_batch_norm=True is never used on the hot path")
+        self.is_batch_norm = bool(is_batch_norm)
         self.use_bias = use_bias
         self.is_dropout = is_dropput          # can never fire in the reference (is_train is never passed)
         self.activation = activation
@@ -173,6 +172,8 @@ class MLPLayer(Layer):
             self.register_parameter("kernel_%d" % i, torch.nn.Parameter(self._kinit((dims[i], dims[i + 1]))))
             if self.use_bias:
                 self.register_parameter("bias_%d" % i, torch.nn.Parameter(self._binit((dims[i + 1],))))
+            if self.is_batch_norm:
+                self.add_module("bn_%d" % i, BatchNormalization(input_dim=dims[i + 1]))
         self.built = True
 
     def forward(self, inputs, is_train=False):
@@ -184,7 +185,13 @@ class MLPLayer(Layer):
         x = inputs
         for i in range(len(self.units)):
             b = getattr(self, "bias_%d" % i) if self.use_bias else None
-            x = Fn.LinearAct.apply(x, getattr(self, "kernel_%d" % i), b, self._act)
+            if self.is_batch_norm:      # MatMul, BiasAdd, BatchNormalization, activation (2.FM/CustomLayers.py:74-81)
+                x = Fn.LinearAct.apply(x, getattr(self, "kernel_%d" % i), b, ops.ACT_CODE[None])
+                x = getattr(self, "bn_%d" % i)(x)
+                if self.activation is not None:
+                    x = Activation(self.activation)(x)
+            else:
+                x = Fn.LinearAct.apply(x, getattr(self, "kernel_%d" % i), b, self._act)
         return x
 
 
@@ -682,3 +689,149 @@ class DINLayer(Layer):
         self._raise_if_oob(flag)
         X_combined = ConcatCols.apply(profile_output, pooled)
         return {"output": self.mlp(X_combined)}
+
+
+# ---------------------------------------------------------------------------------------------------
+# sibling layers on the same gather
+# ---------------------------------------------------------------------------------------------------
+
+class BatchNormalization(Layer):
+    """tf.keras.layers.BatchNormalization() on [B,N]: axis=-1, momentum=0.99, epsilon=1e-3, gamma ones, beta zeros,
+    moving mean 0 / variance 1.  Like Keras it normalises with BATCH statistics (and updates the moving averages)
+    when the module is in training mode -- the reference's train loops call ``model(inputs, training=True)``
+    (3.DCN/ModelManager.py:192) -- and with the moving statistics in eval mode."""
+
+    def __init__(self, momentum=0.99, epsilon=1e-3, center=True, scale=True, input_dim=None):
+        super().__init__()
+        self.momentum, self.epsilon, self.center, self.scale = momentum, epsilon, center, scale
+        self.built = False
+        if input_dim is not None:
+            self.build(input_dim)
+
+    def build(self, n):
+        n = int(n)
+        self.gamma = torch.nn.Parameter(torch.ones(n)) if self.scale else None
+        self.beta = torch.nn.Parameter(torch.zeros(n)) if self.center else None
+        self.register_buffer("moving_mean", torch.zeros(n))
+        self.register_buffer("moving_variance", torch.ones(n))
+        self.built = True
+
+    def forward(self, x):
+        if not self.built:
+            self.build(x.shape[-1])
+            self.to(x.device)
+        return Fn.BatchNorm.apply(x, self.gamma, self.beta, self.moving_mean, self.moving_variance, self.training,
+                                  self.epsilon, self.momentum)
+
+
+class PNNLayer(Layer):
+    """2.FM/CustomLayers.py:696-745 with method='inner' (IpnLayer, :773-792): embed -> [Flatten | pairwise inner
+    products] -> MLP(relu) -> MLP([1], sigmoid).  The lookup, the flatten and the F(F-1)/2 inner products are one
+    kernel; its output IS ``combined_vector``.  method='outer' (OpnLayer) is not on the hot path."""
+
+    def __init__(self, feature_names=["user_tag0", "user_tag1", "item_tag1", "item_tag2", "item_tag3"], feature_dims=20,
+                 embedding_dims=16, mlp_dims=[32, 8], dropout=0, method="inner", kernel_type=None, **kwargs):
+        super().__init__()
+        assert method in ("inner", "outer")
+        if method == "outer":
+            raise NotImplementedError("PNNLayer(method='outer') is outside the accelerated path")
+        self.feature_names = feature_names
+        self.feature_dims = feature_dims
+        self.fields_cnt = len(feature_names)
+        self.embedding_dims = embedding_dims
+        self.mlp_dims = mlp_dims
+        self.method, self.dropout, self.kernel_type = method, dropout, kernel_type
+        F = self.fields_cnt
+        self.embed = Embedding(feature_dims, embedding_dims, embeddings_regularizer="l2")
+        self.MLP_layer1 = MLPLayer(units=mlp_dims, activation="relu", is_dropput=dropout,
+                                   input_dim=F * embedding_dims + F * (F - 1) // 2)
+        self.MLP_layer2 = MLPLayer(units=[1], activation="sigmoid", input_dim=list(mlp_dims)[-1])
+
+    def forward(self, inputs):
+        X = assemble_index(inputs, self.feature_names)
+        flag = ops.new_flag(X.device) if self.check_ids else None
+        combined_vector = Fn.EmbIpn.apply(self.embed.embeddings, X, flag)
+        self._raise_if_oob(flag)
+        output = self.MLP_layer2(self.MLP_layer1(combined_vector))
+        return {"output": output}
+
+
+class NeuralFactorizationMachineLayer(Layer):
+    """3.DCN/CustomLayers.py:451-509: bi-interaction pooling of the categorical embeddings ++ continuous features ->
+    BatchNormalization -> MLP(units, activation) -> MLP([1], sigmoid).  (The first-order table ``w`` is created by
+    the reference but never used, :491-495; it is not allocated here.)"""
+
+    def __init__(self, categorical_features=["uid", "iid", "utag1", "utag2", "utag3", "utag4", "itag1", "itag2",
+                                             "itag3", "itag4"],
+                 continuous_features=["itag4_origin", "itag4_square", "itag4_cube"], feature_dims=160000,
+                 embedding_dims=16, units=[64, 8], activation="relu"):
+        super().__init__()
+        self.categorical_features = categorical_features
+        self.continuous_features = continuous_features
+        self.feature_dims = feature_dims
+        self.embedding_dims = embedding_dims
+        n = embedding_dims + len(continuous_features)
+        self.embed = Embedding(feature_dims, embedding_dims, embeddings_regularizer="l2")
+        self.bn_layer = BatchNormalization(input_dim=n)
+        self.MLP_layer1 = MLPLayer(units=units, activation=activation, input_dim=n)
+        self.MLP_layer2 = MLPLayer(units=[1], activation="sigmoid", input_dim=list(units)[-1])
+
+    def forward(self, inputs):
+        X = assemble_index(inputs, self.categorical_features)
+        flag = ops.new_flag(X.device) if self.check_ids else None
+        cont = _cont_block(inputs, self.continuous_features, X.device)
+        X_cont = torch.cat(cont, dim=1) if cont else None
+        combined_vector = Fn.EmbBiInteraction.apply(self.embed.embeddings, X, X_cont, flag)
+        self._raise_if_oob(flag)
+        combined_vector = self.bn_layer(combined_vector)
+        output = self.MLP_layer2(self.MLP_layer1(combined_vector))
+        return {"output": output}
+
+
+class GSULayer(Layer):
+    """7.SIM/CustomLayers.py:62-127 (general search unit): target item embedding, inner-product attention over the
+    embedded behaviour series with the valid mask, sum pooling, MLP [200,80] + softmax(2).  The series lookup,
+    scores and pooling are one kernel, so ``X_series`` (the [B,T,D] embedded series the reference also returns) is
+    only materialised when ``return_series=True``."""
+
+    def __init__(self, item_categorical_features=["i_goods_id", "i_shop_id", "i_cate_id"],
+                 behavior_series_features=["visited_goods_ids", "visited_shop_ids", "visited_cate_ids"],
+                 feature_dims=1000, embedding_dims=16, activation="Dice", padding_index=0, embedding_layer=None,
+                 l2_reg=0.01, return_series=False):
+        super().__init__()
+        self.item_categorical_features = item_categorical_features
+        assert len(item_categorical_features) == len(behavior_series_features), \
+            "Features to be interacted should match in item and behavior series"
+        self.behavior_series_features = behavior_series_features
+        self.feature_dims = feature_dims
+        self.embedding_dims = embedding_dims
+        self.l2_reg = l2_reg
+        self.embed = embedding_layer if embedding_layer is not None else Embedding(feature_dims, embedding_dims)
+        D = len(item_categorical_features) * embedding_dims
+        self.mlp = make_mlp_layer([200, 80], activation=activation, softmax_units=2, input_dim=2 * D)
+        self.padding_index = padding_index
+        self.return_series = return_series
+
+    def forward(self, inputs):
+        X_item = assemble_index(inputs, self.item_categorical_features)
+        flag = ops.new_flag(X_item.device) if self.check_ids else None
+        q = self.embed(X_item, flag)
+        q = q.reshape(q.shape[0], -1)
+        series_cols = []
+        for name in self.behavior_series_features:
+            t = inputs[name]
+            if not isinstance(t, torch.Tensor):
+                t = torch.as_tensor(t)
+            t = t.to(device=X_item.device, dtype=torch.int64).contiguous()
+            if t.dim() != 2:
+                raise ValueError("behaviour series %r must have shape [B,T]" % name)
+            series_cols.append(t)
+        B, T = series_cols[0].shape
+        series = ops.index_pack(series_cols).reshape(B, T, len(series_cols))      # tf.stack(axis=2)
+        pooled, _ = Fn.IpAttention.apply(self.embed.embeddings, q, series, self.padding_index, flag)
+        self._raise_if_oob(flag)
+        X_combined = ConcatCols.apply(q, pooled)
+        result = {"output": self.mlp(X_combined), "valid_mask": series_cols[0] != self.padding_index}
+        if self.return_series:
+            result["X_series"] = self.embed(series.reshape(B, T * len(series_cols))).reshape(B, T, -1)
+        return result

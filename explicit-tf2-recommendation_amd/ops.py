@@ -499,3 +499,105 @@ def softmax_bwd(y, gy):
     gx = torch.empty_like(y)
     check(lib.rec_softmax_bwd_f32(_ptr(y), _ptr(_f32(gy, "gy")), M, N, _ptr(gx), _stream()), "rec_softmax_bwd_f32")
     return gx
+
+
+# ---------------------------------------------------------------------------------------------------
+# f4: sibling interaction layers on the same gather (PNN inner product, NFM bi-interaction, SIM GSU attention)
+# ---------------------------------------------------------------------------------------------------
+
+def emb_ipn_fwd(table, X, oob=None):
+    """[Flatten(embed(X)) | <e_i,e_j> for i<j]  ->  [B, F*E + F(F-1)/2]  (2.FM/CustomLayers.py:737-745,755-792)."""
+    _table(table, "table"); _i64(X, "X")
+    V, E = table.shape
+    B, F = X.shape
+    W = F * E + F * (F - 1) // 2
+    out = torch.empty((B, W), dtype=torch.float32, device=table.device)
+    check(lib.rec_emb_ipn_fwd_f32(_ptr(table), V, E, table.stride(0), _ptr(X), B, F, _ptr(out), W, _ptr(oob), _stream()),
+          "rec_emb_ipn_fwd_f32")
+    return out
+
+
+def emb_ipn_bwd_vals(out, g, F, E):
+    _f32(out, "out"); _f32(g, "g")
+    B, W = out.shape
+    vals = torch.empty((B * F, E), dtype=torch.float32, device=out.device)
+    check(lib.rec_emb_ipn_bwd_vals_f32(_ptr(out), W, _ptr(g), g.shape[1], B, F, E, _ptr(vals), _stream()),
+          "rec_emb_ipn_bwd_vals_f32")
+    return vals
+
+
+def emb_bi_fwd(table, X, out=None, oob=None):
+    """NFM bi-interaction 0.5*((sum e)^2 - sum e^2) -> the leading E columns of `out` (a [B, >=E] fp32 buffer, fresh
+    [B,E] when None) and sumvec [B,E]."""
+    _table(table, "table"); _i64(X, "X")
+    V, E = table.shape
+    B, F = X.shape
+    if out is None:
+        out = torch.empty((B, E), dtype=torch.float32, device=table.device)
+    _f32(out, "out")
+    S = torch.empty((B, E), dtype=torch.float32, device=table.device)
+    check(lib.rec_emb_bi_fwd_f32(_ptr(table), V, E, table.stride(0), _ptr(X), B, F, _ptr(out), out.shape[1], _ptr(S),
+                                 _ptr(oob), _stream()), "rec_emb_bi_fwd_f32")
+    return out, S
+
+
+def emb_bi_bwd_vals(table, X, g, S):
+    """g: [B, >=E] (only the leading E columns are read)."""
+    _table(table, "table"); _i64(X, "X"); _f32(g, "g"); _f32(S, "S")
+    V, E = table.shape
+    B, F = X.shape
+    vals = torch.empty((B * F, E), dtype=torch.float32, device=table.device)
+    check(lib.rec_emb_bi_bwd_vals_f32(_ptr(table), V, E, table.stride(0), _ptr(X), B, F, _ptr(g), g.shape[1], _ptr(S),
+                                      _ptr(vals), _stream()), "rec_emb_bi_bwd_vals_f32")
+    return vals
+
+
+def ip_attn_fwd(embed, series, q, padding_index, oob=None):
+    """series [B,T,C] int64, q [B,C*E] -> masked scores [B,T], pooled [B,C*E]  (7.SIM/CustomLayers.py:88-96)."""
+    _table(embed, "embed"); _i64(series, "series"); _f32(q, "q")
+    V, E = embed.shape
+    B, T, C = series.shape
+    D = C * E
+    scores = torch.empty((B, T), dtype=torch.float32, device=embed.device)
+    pooled = torch.empty((B, D), dtype=torch.float32, device=embed.device)
+    check(lib.rec_ip_attn_fwd_f32(_ptr(embed), embed.stride(0), V, E, C, _ptr(series), B, T, _ptr(q), q.shape[1],
+                                  int(padding_index), _ptr(scores), _ptr(pooled), D, _ptr(oob), _stream()),
+          "rec_ip_attn_fwd_f32")
+    return scores, pooled
+
+
+def ip_attn_bwd(embed, series, q, padding_index, scores, gpooled):
+    _table(embed, "embed"); _i64(series, "series"); _f32(q, "q"); _f32(scores, "scores"); _f32(gpooled, "gpooled")
+    V, E = embed.shape
+    B, T, C = series.shape
+    D = C * E
+    gkeys = torch.empty((B, T, D), dtype=torch.float32, device=embed.device)
+    gq = torch.empty((B, D), dtype=torch.float32, device=embed.device)
+    check(lib.rec_ip_attn_bwd_f32(_ptr(embed), embed.stride(0), V, E, C, _ptr(series), B, T, _ptr(q), q.shape[1],
+                                  int(padding_index), _ptr(scores), _ptr(gpooled), gpooled.shape[1], _ptr(gkeys),
+                                  _ptr(gq), _stream()), "rec_ip_attn_bwd_f32")
+    return gkeys, gq
+
+
+def batchnorm_fwd(x, gamma, beta, moving_mean, moving_var, training, eps=1e-3, momentum=0.99, save=True):
+    """Keras BatchNormalization on [B,N]; moving statistics are updated in place when training."""
+    _f32(x, "x")
+    B, N = x.shape
+    y = torch.empty_like(x)
+    xhat = torch.empty_like(x) if save else None
+    rstd = torch.empty(N, dtype=torch.float32, device=x.device) if save else None
+    check(lib.rec_batchnorm_fwd_f32(_ptr(x), N, B, N, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
+                                    1 if training else 0, _ptr(moving_mean), _ptr(moving_var), _ptr(y), _ptr(xhat),
+                                    _ptr(rstd), _stream()), "rec_batchnorm_fwd_f32")
+    return y, xhat, rstd
+
+
+def batchnorm_bwd(g, xhat, rstd, gamma, training):
+    _f32(g, "g")
+    B, N = g.shape
+    gx = torch.empty_like(g)
+    ggamma = torch.empty(N, dtype=torch.float32, device=g.device)
+    gbeta = torch.empty(N, dtype=torch.float32, device=g.device)
+    check(lib.rec_batchnorm_bwd_f32(_ptr(g), _ptr(xhat), _ptr(rstd), B, N, _ptr(gamma), 1 if training else 0, _ptr(gx),
+                                    _ptr(ggamma), _ptr(gbeta), _stream()), "rec_batchnorm_bwd_f32")
+    return gx, ggamma, gbeta

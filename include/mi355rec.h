@@ -310,6 +310,48 @@ int rec_layernorm_bwd_f32(const float* gy, const float* xhat, const float* rstd,
 int rec_softmax_fwd_f32(const float* x, int64_t M, int N, float* y, void* stream);
 int rec_softmax_bwd_f32(const float* y, const float* gy, int64_t M, int N, float* gx, void* stream);
 
+/* ==== SURVEY.md section 8 row f4: sibling interaction layers that share the gather ======================= */
+
+/* ---- PNN inner product: Embedding -> Flatten ++ IpnLayer (2.FM/CustomLayers.py:729-745, :755-792).
+ * out[b, f*E + d] = table[X[b,f], d];  out[b, F*E + p(i,j)] = <e_i, e_j> for i < j in the row-major order of the
+ * upper triangle (the order tf.boolean_mask keeps).  ld_out >= F*E + F*(F-1)/2: `out` IS the reference's
+ * combined_vector.  F <= 255. */
+int rec_emb_ipn_fwd_f32(const float* table, int64_t V, int E, int64_t ld, const int64_t* X, int64_t B, int F,
+                        float* out, int64_t ld_out, int* oob_flag, void* stream);
+/* IndexedSlices values of that lookup: vals[b*F+i, :] = g[b, i*E:(i+1)*E] + sum_{j != i} g[b, F*E + p(i,j)] * e_j,
+ * with the rows e read back from the forward output `out`. */
+int rec_emb_ipn_bwd_vals_f32(const float* out, int64_t ld_out, const float* g, int64_t ld_g, int64_t B, int F, int E,
+                             float* vals, void* stream);
+
+/* ---- NFM bi-interaction pooling (3.DCN/CustomLayers.py:499-501): out[b,d] = 0.5*((sum_f e_fd)^2 - sum_f e_fd^2),
+ * written with row stride ld_out (so it can land in the leading columns of [second_order | X_cont]); sumvec [B,E]
+ * = sum_f e_f is kept for the backward  vals[b*F+f, d] = g[b,d] * (sumvec[b,d] - e_fd). */
+int rec_emb_bi_fwd_f32(const float* table, int64_t V, int E, int64_t ld, const int64_t* X, int64_t B, int F, float* out,
+                       int64_t ld_out, float* sumvec, int* oob_flag, void* stream);
+int rec_emb_bi_bwd_vals_f32(const float* table, int64_t V, int E, int64_t ld, const int64_t* X, int64_t B, int F,
+                            const float* g, int64_t ld_g, const float* sumvec, float* vals, void* stream);
+
+/* ---- SIM GSU inner-product attention + sum pooling (7.SIM/CustomLayers.py:88-96, 107-118).
+ * series int64 [B,T,C]; key k_t = concat_r embed[series[b,t,r]] (D = C*E <= 256); valid[b,t] = series[b,t,0] !=
+ * padding_index; scores[b,t] = valid * <q_b, k_t> (the masked scores); pooled[b,:] = sum_t scores[b,t] * k_t. */
+int rec_ip_attn_fwd_f32(const float* embed, int64_t ld, int64_t V, int E, int C, const int64_t* series, int64_t B, int T,
+                        const float* q, int64_t ld_q, int64_t padding_index, float* scores, float* pooled,
+                        int64_t ld_pooled, int* oob_flag, void* stream);
+/* gkeys [B,T,D] = IndexedSlices values of the series lookups, gq [B,D] = gradient of the target vector. */
+int rec_ip_attn_bwd_f32(const float* embed, int64_t ld, int64_t V, int E, int C, const int64_t* series, int64_t B, int T,
+                        const float* q, int64_t ld_q, int64_t padding_index, const float* scores, const float* gpooled,
+                        int64_t ld_gpooled, float* gkeys, float* gq, void* stream);
+
+/* ---- tf.keras.layers.BatchNormalization on [B,N] (3.DCN/CustomLayers.py:466,504; 2.FM/CustomLayers.py:69,78-79).
+ * training != 0: batch mean / biased batch variance, moving statistics updated in place with `momentum`;
+ * training == 0: moving statistics.  xhat [B,N] and rstd [N] are saved for the backward (may be NULL at inference).
+ * gamma / beta may be NULL (scale / center off). */
+int rec_batchnorm_fwd_f32(const float* x, int64_t ld_x, int64_t B, int N, const float* gamma, const float* beta,
+                          float eps, float momentum, int training, float* moving_mean, float* moving_var, float* y,
+                          float* xhat, float* rstd, void* stream);
+int rec_batchnorm_bwd_f32(const float* g, const float* xhat, const float* rstd, int64_t B, int N, const float* gamma,
+                          int training, float* gx, float* ggamma, float* gbeta, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -509,3 +509,122 @@ def shard_bucketize(ids, rows_per_shard, n_shard):
     counts = np.bincount(owner, minlength=n_shard).astype(np.int64)
     local = ids[perm] - owner[perm] * rows_per_shard
     return perm, counts, local
+
+
+# ---------------------------------------------------------------------------------------------------
+# sibling interaction layers (closed forms + hand-derived backward)
+# ---------------------------------------------------------------------------------------------------
+
+def pair_list(F):
+    """(i, j), i < j, in the row-major order of the upper triangle -- the order tf.boolean_mask keeps
+    (2.FM/CustomLayers.py:764-771) and the order of the explicit double loop (:662-665)."""
+    return [(i, j) for i in range(F - 1) for j in range(i + 1, F)]
+
+
+def ipn_forward(table, X, dt=np.float32):
+    """PNNLayer.call front end with method='inner' (2.FM/CustomLayers.py:737-745; IpnLayer :773-792):
+    combined_vector = [Flatten(embed(X)) | reduce_sum_e(e_i * e_j) for i<j]."""
+    e = embedding_lookup(table, X).astype(dt)                    # [B,F,E]
+    B, F, E = e.shape
+    pairs = pair_list(F)
+    prod = np.zeros((B, len(pairs)), dt)
+    for p, (i, j) in enumerate(pairs):
+        prod[:, p] = (e[:, i, :] * e[:, j, :]).sum(axis=1)
+    return np.concatenate([e.reshape(B, F * E), prod], axis=1)
+
+
+def ipn_backward_vals(table, X, g, dt=np.float32):
+    """Per-lookup gradient rows [B*F, E] of ipn_forward for an upstream gradient g [B, F*E + P]."""
+    e = embedding_lookup(table, X).astype(dt)
+    B, F, E = e.shape
+    ge = g[:, :F * E].reshape(B, F, E).astype(dt).copy()
+    for p, (i, j) in enumerate(pair_list(F)):
+        gp = g[:, F * E + p].astype(dt)[:, None]
+        ge[:, i, :] += gp * e[:, j, :]
+        ge[:, j, :] += gp * e[:, i, :]
+    return ge.reshape(B * F, E)
+
+
+def bi_interaction_forward(table, X, dt=np.float32):
+    """3.DCN/CustomLayers.py:499-501: 0.5 * (square(reduce_sum(e, 1)) - reduce_sum(square(e), 1))  -> [B,E]."""
+    e = embedding_lookup(table, X).astype(dt)
+    return (0.5 * (np.square(e.sum(axis=1)) - np.square(e).sum(axis=1))).astype(dt)
+
+
+def bi_interaction_backward_vals(table, X, g, dt=np.float32):
+    e = embedding_lookup(table, X).astype(dt)
+    B, F, E = e.shape
+    S = e.sum(axis=1, keepdims=True)
+    return (g.astype(dt)[:, None, :] * (S - e)).reshape(B * F, E)
+
+
+def batchnorm_forward(x, gamma, beta, mov_mean, mov_var, training, eps=1e-3, momentum=0.99, dt=np.float32):
+    """tf.keras.layers.BatchNormalization on [B,N], non-fused path: tf.nn.moments (biased variance) when training,
+    moving statistics otherwise; returns (y, new_moving_mean, new_moving_var)."""
+    x = x.astype(dt)
+    gamma, beta = np.asarray(gamma, dt), np.asarray(beta, dt)
+    mov_mean, mov_var = np.asarray(mov_mean, dt), np.asarray(mov_var, dt)
+    if training:
+        mean = x.mean(axis=0)
+        var = np.square(x - mean).mean(axis=0)
+        new_mean = mov_mean * momentum + mean * (1 - momentum)
+        new_var = mov_var * momentum + var * (1 - momentum)
+    else:
+        mean, var, new_mean, new_var = mov_mean, mov_var, mov_mean, mov_var
+    y = (x - mean) / np.sqrt(var + eps) * gamma + beta
+    return y.astype(dt), new_mean.astype(dt), new_var.astype(dt)
+
+
+def batchnorm_backward(x, gamma, g, eps=1e-3, dt=np.float32):
+    """Training-mode backward (batch statistics are functions of x)."""
+    x = x.astype(dt); g = g.astype(dt); gamma = np.asarray(gamma, dt)
+    B = x.shape[0]
+    mean = x.mean(axis=0)
+    var = np.square(x - mean).mean(axis=0)
+    rstd = 1.0 / np.sqrt(var + eps)
+    xhat = (x - mean) * rstd
+    gbeta = g.sum(axis=0)
+    ggamma = (g * xhat).sum(axis=0)
+    gx = gamma * rstd * (g - gbeta / B - xhat * ggamma / B)
+    return gx.astype(dt), ggamma.astype(dt), gbeta.astype(dt)
+
+
+def nfm_forward(p, X, X_cont, training=True, dt=np.float32):
+    """NeuralFactorizationMachineLayer.call (3.DCN/CustomLayers.py:476-509).  p: embed, bn_gamma, bn_beta,
+    bn_mean, bn_var, k1/b1 lists (MLP_layer1, activation on every layer), k2/b2 (MLP_layer2, sigmoid)."""
+    second = bi_interaction_forward(p["embed"], X, dt)
+    comb = np.concatenate([second, X_cont.astype(dt)], axis=1)
+    comb, _, _ = batchnorm_forward(comb, p["bn_gamma"], p["bn_beta"], p["bn_mean"], p["bn_var"], training, dt=dt)
+    h = mlp_forward(comb, p["k1"], p["b1"], p.get("activation", "relu"), dt)
+    return mlp_forward(h, p["k2"], p["b2"], "sigmoid", dt)
+
+
+def pnn_forward(p, X, dt=np.float32):
+    """PNNLayer.call, method='inner' (2.FM/CustomLayers.py:729-752)."""
+    comb = ipn_forward(p["embed"], X, dt)
+    h = mlp_forward(comb, p["k1"], p["b1"], "relu", dt)
+    return mlp_forward(h, p["k2"], p["b2"], "sigmoid", dt)
+
+
+def ip_attention_forward(table, q, series, padding_index=0, dt=np.float32):
+    """GSULayer.inner_product_attention over the embedded series (7.SIM/CustomLayers.py:88-96,107-118).
+    series [B,T,C] -> (masked scores [B,T], pooled [B,C*E])."""
+    B, T, C = series.shape
+    k = embedding_lookup(table, series.reshape(B, T * C)).astype(dt).reshape(B, T, -1)     # [B,T,D]
+    valid = (series[:, :, 0] != padding_index).astype(dt)
+    scores = np.einsum("be,ble->bl", q.astype(dt), k) * valid
+    pooled = np.einsum("bl,ble->be", scores, k)
+    return scores.astype(dt), pooled.astype(dt)
+
+
+def ip_attention_backward(table, q, series, gpooled, padding_index=0, dt=np.float32):
+    """-> (gkeys [B,T,D], gq [B,D])."""
+    B, T, C = series.shape
+    k = embedding_lookup(table, series.reshape(B, T * C)).astype(dt).reshape(B, T, -1)
+    valid = (series[:, :, 0] != padding_index).astype(dt)
+    q = q.astype(dt); gpooled = gpooled.astype(dt)
+    scores = np.einsum("be,ble->bl", q, k) * valid
+    gs = np.einsum("be,ble->bl", gpooled, k) * valid             # d pooled / d score, masked
+    gq = np.einsum("bl,ble->be", gs, k)
+    gkeys = scores[:, :, None] * gpooled[:, None, :] + gs[:, :, None] * q[:, None, :]
+    return gkeys.astype(dt), gq.astype(dt)

@@ -222,3 +222,79 @@ class KerasAdam:
                 v.add_((g * g - v) * (1 - self.b2))
             q.sub_(lr_t * m / (torch.sqrt(v) + self.eps))
             q.grad = None
+
+
+# ---------------------------------------------------------------------------------------------------
+# sibling interaction layers, op for op as the TF source writes them
+# ---------------------------------------------------------------------------------------------------
+
+def shared_fields_interaction(x):
+    """SharedFieldsInteraction (2.FM/CustomLayers.py:755-771): x1 * x2 broadcast to [B,F,F,E], strict upper
+    triangle kept by a boolean mask in row-major order -> [B, F(F-1)/2, E]."""
+    B, Fn, E = x.shape
+    inter = x.unsqueeze(1) * x.unsqueeze(2)
+    mask = torch.triu(torch.ones(Fn, Fn), diagonal=1) > 0
+    return inter[:, mask, :]
+
+
+def ipn(x):
+    """IpnLayer.call (:788-792): reduce_sum over the embedding axis."""
+    return shared_fields_interaction(x).sum(dim=2)
+
+
+def pnn_combined(table, X, sparse=False):
+    """PNNLayer.call (:737-745): emb -> [Flatten(emb) | IpnLayer(emb)]."""
+    emb = lookup(table, X, sparse)
+    return torch.cat([emb.reshape(emb.shape[0], -1), ipn(emb)], dim=1)
+
+
+def pnn_forward(p, X, sparse=False):
+    comb = pnn_combined(p["embed"], X, sparse)
+    h = mlp(comb, p["k1"], p["b1"], "relu")
+    return mlp(h, p["k2"], p["b2"], "sigmoid")
+
+
+def bi_interaction(table, X, sparse=False):
+    """3.DCN/CustomLayers.py:499-501."""
+    emb = lookup(table, X, sparse)
+    sum_of_square = torch.sum(torch.square(emb), dim=1)
+    square_of_sum = torch.square(torch.sum(emb, dim=1))
+    return 0.5 * (square_of_sum - sum_of_square)
+
+
+def batchnorm(x, gamma, beta, mov_mean, mov_var, training, eps=BN_EPS):
+    """Keras BatchNormalization (non-fused, [B,N]); the moving-average update is not modelled here (see layers_np)."""
+    if training:
+        mean = x.mean(dim=0)
+        var = torch.square(x - mean).mean(dim=0)
+    else:
+        mean, var = mov_mean, mov_var
+    return (x - mean) * torch.rsqrt(var + eps) * gamma + beta
+
+
+def nfm_forward(p, X, X_cont, training=True, sparse=False):
+    """NeuralFactorizationMachineLayer.call (3.DCN/CustomLayers.py:476-509)."""
+    comb = torch.cat([bi_interaction(p["embed"], X, sparse), X_cont], dim=1)
+    comb = batchnorm(comb, p["bn_gamma"], p["bn_beta"], p["bn_mean"], p["bn_var"], training)
+    h = mlp(comb, p["k1"], p["b1"], p.get("activation", "relu"))
+    return mlp(h, p["k2"], p["b2"], "sigmoid")
+
+
+def ip_attention(table, q, series, padding_index=0, sparse=False):
+    """GSULayer (7.SIM/CustomLayers.py:88-96,107-118): embedded series [B,T,C*E], einsum scores, valid mask,
+    einsum pooling.  -> (masked scores, pooled)."""
+    B, T, C = series.shape
+    k = lookup(table, series.reshape(B, T * C), sparse).reshape(B, T, -1)
+    valid = (series[:, :, 0] != padding_index).to(torch.float32)
+    scores = torch.einsum("be,ble->bl", q, k) * valid
+    pooled = torch.einsum("bl,ble->be", scores, k)
+    return scores, pooled
+
+
+def gsu_combined(p, item_ids, series, padding_index=0, sparse=False):
+    """GSULayer.call up to X_combined = [Flatten(embed(item ids)) | pooled] (7.SIM/CustomLayers.py:98-122); the MLP
+    that follows is the same make_mlp_layer stack din_forward restates."""
+    q = lookup(p["embed"], item_ids, sparse)
+    q = q.reshape(q.shape[0], -1)
+    _, pooled = ip_attention(p["embed"], q, series, padding_index, sparse)
+    return torch.cat([q, pooled], dim=1)

@@ -95,6 +95,37 @@ def din_params(seed, V, E, n_user=5, n_item=3, act="dice", H=36, mlp_units=(200,
     }
 
 
+def nfm_params(seed, V, E, n_cont=3, units=(64, 8), scale=0.3):
+    """NeuralFactorizationMachineLayer (3.DCN/CustomLayers.py:451-474): embed, BatchNormalization(E+n_cont), MLP."""
+    r = rng(seed)
+    n = E + n_cont
+    dims = [n] + list(units)
+    return {
+        "embed": r.uniform(-scale, scale, size=(V, E)).astype(np.float32),
+        "bn_gamma": r.uniform(0.5, 1.5, size=(n,)).astype(np.float32),
+        "bn_beta": r.uniform(-0.2, 0.2, size=(n,)).astype(np.float32),
+        "bn_mean": r.uniform(-0.1, 0.1, size=(n,)).astype(np.float32),
+        "bn_var": r.uniform(0.5, 1.5, size=(n,)).astype(np.float32),
+        "k1": [glorot(r, dims[i], dims[i + 1]) for i in range(len(dims) - 1)],
+        "b1": [r.uniform(-0.1, 0.1, size=(dims[i + 1],)).astype(np.float32) for i in range(len(dims) - 1)],
+        "k2": [glorot(r, dims[-1], 1)],
+        "b2": [r.uniform(-0.1, 0.1, size=(1,)).astype(np.float32)],
+    }
+
+
+def pnn_params(seed, V, F, E, mlp_dims=(32, 8), scale=0.3):
+    """PNNLayer, method='inner' (2.FM/CustomLayers.py:705-727)."""
+    r = rng(seed)
+    dims = [F * E + F * (F - 1) // 2] + list(mlp_dims)
+    return {
+        "embed": r.uniform(-scale, scale, size=(V, E)).astype(np.float32),
+        "k1": [glorot(r, dims[i], dims[i + 1]) for i in range(len(dims) - 1)],
+        "b1": [r.uniform(-0.1, 0.1, size=(dims[i + 1],)).astype(np.float32) for i in range(len(dims) - 1)],
+        "k2": [glorot(r, dims[-1], 1)],
+        "b2": [r.uniform(-0.1, 0.1, size=(1,)).astype(np.float32)],
+    }
+
+
 def to_torch(obj, dtype=None, requires_grad=False, device=None):
     import torch
     if isinstance(obj, dict):
