@@ -2,6 +2,7 @@
 //   PNN inner product      2.FM/CustomLayers.py:729-745 (PNNLayer.call), :755-792 (SharedFieldsInteraction, IpnLayer)
 //   NFM bi-interaction     3.DCN/CustomLayers.py:493-503
 //   SIM GSU inner-product attention + sum pooling   7.SIM/CustomLayers.py:88-96
+//   FFM field-aware second order                    2.FM/CustomLayers.py:398-425, 428-462
 // Each is the gather of embedding.hip with a different epilogue, so each is ONE kernel forward (ids -> rows -> the
 // layer's output, nothing materialised in between) and ONE kernel backward that produces the per-lookup gradient rows
 // (IndexedSlices values); de-duplication is the shared plan + segment sum of dedup.hip.  All HBM-bound on the random
@@ -427,4 +428,149 @@ extern "C" int rec_ip_attn_bwd_f32(const float* embed, int64_t ld, int64_t V, in
   if (B > 0 && (!gpooled || !gkeys || !gq || ld_gpooled < (int64_t)C * E)) return REC_E_ARG;
   return ip_attn_launch(true, embed, ld, V, E, C, series, B, T, q, ld_q, padding_index, const_cast<float*>(scores),
                         nullptr, 0, gpooled, ld_gpooled, gkeys, gq, nullptr, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FFM, field-aware second order (FieldAwareInteractionLayer, 2.FM/CustomLayers.py:428-462; the loop form
+// FFMRankingLayer.call :398-425 computes the same numbers from F separate tables).
+// Table v [V, F, E]: v[id, c, :] is the vector id uses against field c, so ONE id's F vectors are contiguous
+// (F*E*4 bytes = 13 lines at F=26, E=16) and the workgroup of an example reads whole rows.
+//   z[b] = bias + sum_a w[X[b,a]] + sum_{a<c} < v[X[b,a], c, :], v[X[b,c], a, :] >
+// Every element v[X[b,a], c, :] (c != a) is used exactly once, so nothing is staged: one lane per (pair, 4 dims).
+// ------------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void ffm_fwd_kernel(const float* __restrict__ v, int64_t ld_v,
+                                                      const float* __restrict__ w, int64_t ld_w,
+                                                      const float* __restrict__ bias, int64_t V, int E,
+                                                      const int64_t* __restrict__ X, int64_t B, int F,
+                                                      float* __restrict__ z, float* __restrict__ prob, int* oob) {
+  extern __shared__ int ffm_lds[];
+  const int P = F * (F - 1) / 2;
+  int* ids = ffm_lds;                                                    // [F]
+  float* red = reinterpret_cast<float*>(ids + F);                        // [4]
+  unsigned char* pi = reinterpret_cast<unsigned char*>(red + 4);         // [P]
+  unsigned char* pj = pi + P;
+  const int tid = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  bool bad = false;
+  for (int i = tid; i < F; i += 256) {
+    int64_t id = X[b * F + i];
+    bool ok = (uint64_t)id < (uint64_t)V;
+    bad |= !ok;
+    ids[i] = ok ? (int)id : -1;
+  }
+  if (bad && oob) *oob = 1;
+  for (int i = tid; i < F - 1; i += 256) {
+    int p = pair_index(i, i + 1, F);
+    for (int j = i + 1; j < F; ++j, ++p) { pi[p] = (unsigned char)i; pj[p] = (unsigned char)j; }
+  }
+  __syncthreads();
+  constexpr int W = VEC ? 4 : 1;
+  const int EL = E / W;
+  float acc = 0.f;
+  for (int i = tid; i < P * EL; i += 256) {
+    int p = i / EL, c4 = i - p * EL;
+    int a = pi[p], c = pj[p];
+    int ia = ids[a], ic = ids[c];
+    if (ia < 0 || ic < 0) continue;                        // an out-of-range id contributes zeros
+    const float* pa = v + (int64_t)ia * ld_v + c * E + c4 * W;
+    const float* pc = v + (int64_t)ic * ld_v + a * E + c4 * W;
+    if constexpr (VEC) {
+      float4 x = *reinterpret_cast<const float4*>(pa);
+      float4 y = *reinterpret_cast<const float4*>(pc);
+      acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    } else {
+      acc += pa[0] * pc[0];
+    }
+  }
+  for (int i = tid; i < F; i += 256)
+    if (ids[i] >= 0) acc += w[(int64_t)ids[i] * ld_w];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    float zz = bias[0] + ((red[0] + red[1]) + (red[2] + red[3]));
+    if (z) z[b] = zz;
+    if (prob) prob[b] = sigmoid_acc(zz);
+  }
+}
+
+// Rows of the de-duplicated gradient of v, straight from the plan of rec_dedup_plan_i64 over X (n = B*F lookups):
+//   g_rows[u, c, :] = sum over the lookups (b,a) of unique id u, in plan order, of gz[b] * v[X[b,c], a, :]   (c != a)
+// One workgroup per unique id (rows u >= n_uniq are zero-filled like every padded tail of the plan).
+template <bool VEC>
+__global__ __launch_bounds__(128) void ffm_bwd_rows_kernel(const float* __restrict__ v, int64_t ld_v, int64_t V, int E,
+                                                           const int64_t* __restrict__ X, int F,
+                                                           const float* __restrict__ gz,
+                                                           const int32_t* __restrict__ perm,
+                                                           const int32_t* __restrict__ seg_start,
+                                                           const int64_t* __restrict__ n_uniq,
+                                                           float* __restrict__ g_rows) {
+  constexpr int W = VEC ? 4 : 1;
+  const int EL = E / W;
+  const int64_t u = blockIdx.x;
+  float* out = g_rows + u * (int64_t)F * E;
+  const bool live = u < *n_uniq;
+  const int s = live ? seg_start[u] : 0, e = live ? seg_start[u + 1] : 0;
+  for (int item = threadIdx.x; item < F * EL; item += 128) {
+    int c = item / EL, c4 = item - c * EL;
+    float acc[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) acc[k] = 0.f;
+    for (int r = s; r < e; ++r) {
+      int lr = perm[r];
+      int b = lr / F, a = lr - b * F;
+      if (a == c) continue;
+      int64_t id = X[(int64_t)b * F + c];
+      if ((uint64_t)id >= (uint64_t)V) continue;
+      float g = gz[b];
+      const float* src = v + id * ld_v + a * E + c4 * W;
+      if constexpr (VEC) {
+        float4 x = *reinterpret_cast<const float4*>(src);
+        acc[0] += g * x.x; acc[1] += g * x.y; acc[2] += g * x.z; acc[3] += g * x.w;
+      } else {
+        acc[0] += g * src[0];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) out[c * E + c4 * W + k] = acc[k];
+  }
+}
+
+extern "C" int rec_ffm_fwd_f32(const float* v, int64_t ld_v, const float* w, int64_t ld_w, const float* bias, int64_t V,
+                               int E, const int64_t* X, int64_t B, int F, float* z, float* prob, int* oob_flag,
+                               void* stream) {
+  if (V <= 0 || V > INT32_MAX || E <= 0 || F <= 0 || F > 255 || ld_v < (int64_t)F * E || ld_w < 1 || B < 0)
+    return REC_E_ARG;
+  if (B == 0) return REC_OK;
+  if (!v || !w || !bias || !X || (!z && !prob)) return REC_E_ARG;
+  const size_t lds = (size_t)F * 4 + 16 + (size_t)F * (F - 1);
+  const bool vec = (E & 3) == 0 && (ld_v & 3) == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL((ffm_fwd_kernel<true>), dim3((unsigned)B), dim3(256), lds, as_stream(stream), v, ld_v, w, ld_w,
+                       bias, V, E, X, B, F, z, prob, oob_flag);
+  else
+    hipLaunchKernelGGL((ffm_fwd_kernel<false>), dim3((unsigned)B), dim3(256), lds, as_stream(stream), v, ld_v, w, ld_w,
+                       bias, V, E, X, B, F, z, prob, oob_flag);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_ffm_bwd_rows_f32(const float* v, int64_t ld_v, int64_t V, int E, const int64_t* X, int64_t B, int F,
+                                    const float* gz, const int32_t* perm, const int32_t* seg_start,
+                                    const int64_t* n_uniq, float* g_rows, void* stream) {
+  if (V <= 0 || E <= 0 || F <= 0 || ld_v < (int64_t)F * E || B < 0 || B * F > INT32_MAX) return REC_E_ARG;
+  if (B == 0) return REC_OK;
+  if (!v || !X || !gz || !perm || !seg_start || !n_uniq || !g_rows) return REC_E_ARG;
+  const bool vec = (E & 3) == 0 && (ld_v & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(g_rows)) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL((ffm_bwd_rows_kernel<true>), dim3((unsigned)(B * F)), dim3(128), 0, as_stream(stream), v, ld_v,
+                       V, E, X, F, gz, perm, seg_start, n_uniq, g_rows);
+  else
+    hipLaunchKernelGGL((ffm_bwd_rows_kernel<false>), dim3((unsigned)(B * F)), dim3(128), 0, as_stream(stream), v, ld_v,
+                       V, E, X, F, gz, perm, seg_start, n_uniq, g_rows);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
 }

@@ -409,3 +409,26 @@ class BatchNorm(torch.autograd.Function):
         xhat, rstd, gamma = ctx.saved_tensors
         gx, ggamma, gbeta = ops.batchnorm_bwd(g.contiguous(), xhat, rstd, gamma, ctx.training)
         return gx, ggamma, gbeta, None, None, None, None, None
+
+
+class FFM(torch.autograd.Function):
+    """FFM logit: bias + first order + field-aware second order, fused with the lookups
+    (2.FM/CustomLayers.py:398-425 / 428-462, 480-494).  v [V,F,E], w [V,1], bias [1], X [B,F] -> z [B]."""
+
+    @staticmethod
+    def forward(ctx, v, w, bias, X, oob):
+        z, _ = ops.ffm_fwd(v, w, bias, X, oob=oob)
+        ctx.save_for_backward(v, X)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        v, X = ctx.saved_tensors
+        V, F, E = v.shape
+        B = X.shape[0]
+        gz = gz.contiguous()
+        plan = ops.DedupPlan(X, V)
+        rows = ops.ffm_bwd_rows(v, X, gz, plan)
+        g_v = SparseRowGrad(plan.uniq_ids, rows, plan.n_uniq, (V, F, E)).to_sparse()
+        g_w = _sparse_grad(plan, gz.reshape(B, 1), 1, (V, 1), row_div=F)
+        return g_v, g_w, ops.colsum(gz.reshape(B, 1)), None, None

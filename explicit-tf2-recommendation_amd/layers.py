@@ -835,3 +835,60 @@ class GSULayer(Layer):
         if self.return_series:
             result["X_series"] = self.embed(series.reshape(B, T * len(series_cols))).reshape(B, T, -1)
         return result
+
+
+class FieldAwareInteractionLayer(Layer):
+    """Holder of the field-aware table ``v`` [feature_dims, fields_cnt, embedding_dims] (2.FM/CustomLayers.py:428-434):
+    v[id, c, :] is the vector id uses against field c.  The interaction itself is fused into Fn.FFM."""
+
+    def __init__(self, fields_cnt, feature_dims=20, embedding_dims=16, **kwargs):
+        super().__init__()
+        self.v = torch.nn.Parameter(_uniform((feature_dims, fields_cnt, embedding_dims), 0.05))
+
+
+class FFMLayer(Layer):
+    """2.FM/CustomLayers.py:465-497: sigmoid(bias + sum_f w[x_f] + sum_{a<c} <v[x_a,c,:], v[x_c,a,:]>).  (The reference
+    builds its FieldAwareInteractionLayer with the DEFAULT feature_dims=20 / embedding_dims=16, ignoring the layer's
+    own arguments, :476; the layer's arguments are used here.)"""
+
+    def __init__(self, feature_names=["item_tag1", "item_tag2", "item_tag3", "user_tag0", "user_tag1"], feature_dims=20,
+                 embedding_dims=16, **kwargs):
+        super().__init__()
+        self.feature_names = feature_names
+        self.feature_dims = feature_dims
+        self.fields_cnt = len(feature_names)
+        self.embedding_dims = embedding_dims
+        self.bias = torch.nn.Parameter(_uniform((1,), 0.05))
+        self.w = torch.nn.Parameter(_uniform((feature_dims, 1), 0.05))
+        self.fa_interaction_layer = FieldAwareInteractionLayer(self.fields_cnt, feature_dims, embedding_dims)
+
+    def logit(self, inputs):
+        X = assemble_index(inputs, self.feature_names)
+        flag = ops.new_flag(X.device) if self.check_ids else None
+        z = Fn.FFM.apply(self.fa_interaction_layer.v, self.w, self.bias, X, flag)
+        self._raise_if_oob(flag)
+        return z
+
+    def forward(self, inputs):
+        z = self.logit(inputs)
+        return {"output": Fn.Sigmoid.apply(z).reshape(-1, 1)}
+
+
+class FFMRankingLayer(FFMLayer):
+    """2.FM/CustomLayers.py:370-425, the loop form: ``embedding_list[i]`` is the table used against field i and
+    ebd_out[i][:, j] * ebd_out[j][:, i] = table_i[x_j] * table_j[x_i].  Same numbers as FFMLayer with
+    v[id, i, :] = embedding_list[i][id, :]; the F tables are kept interleaved per id (one id's F vectors contiguous)
+    and exposed as strided views."""
+
+    def __init__(self, feature_names=["item_tag1", "item_tag2", "item_tag3"], feature_dims=20, embedding_dims=16,
+                 **kwargs):
+        super().__init__(feature_names=feature_names, feature_dims=feature_dims, embedding_dims=embedding_dims)
+
+    @property
+    def embedding_list(self):
+        v = self.fa_interaction_layer.v
+        return [v[:, i, :] for i in range(self.fields_cnt)]
+
+
+class PNNRankingLayer(PNNLayer):
+    """2.FM/CustomLayers.py:536-598 (the loop form, InnerProductNetwork :601-624): same numbers as PNNLayer."""

@@ -50,7 +50,9 @@ class KerasAdam:
                 plan = ops.DedupPlan(idx, p.shape[0])
                 rows = plan.segment_sum(vals, vals.shape[1])
                 fn = ops.adam_sparse_keras if self.sparse_mode == "keras" else ops.adam_rows
-                fn(p.data, m, v, plan.uniq_ids, rows, plan.n_uniq, t, self.lr, self.b1, self.b2, self.eps)
+                V0 = p.shape[0]        # tables with more than two axes (FFM's [V,F,E]) are rows of F*E floats
+                fn(p.data.reshape(V0, -1), m.reshape(V0, -1), v.reshape(V0, -1), plan.uniq_ids, rows, plan.n_uniq, t,
+                   self.lr, self.b1, self.b2, self.eps)
             else:
                 ops.adam_dense(p.data, m, v, g.contiguous(), t, self.lr, self.b1, self.b2, self.eps)
             p.grad = None
@@ -131,6 +133,15 @@ class ModelManager:
                     u_feature_dims=self.feature_dims, i_feature_dims=self.feature_dims)
             else:
                 self.layer = CL.DSSMTwoTowerRetrievalLayer(**model_params)
+        elif layer_name == "ffm_ranking":                  # 2.FM/ModelManager.py:76-77
+            self.layer = CL.FFMRankingLayer(**kw, **model_params)
+        elif layer_name == "pnn_ranking":                  # 2.FM/ModelManager.py:78-82 (method 'inner' is accelerated)
+            self.layer = CL.PNNRankingLayer(**kw, method=model_params.get("method", "inner"),
+                                            kernel_type=model_params.get("kernel_type", "mat"))
+        elif layer_name == "NFM":                          # 3.DCN/ModelManager.py:78-79
+            self.layer = CL.NeuralFactorizationMachineLayer(
+                categorical_features=self.feature_names, continuous_features=self.continuous_features,
+                feature_dims=self.feature_dims, embedding_dims=self.embedding_dims, **model_params)
         elif layer_name == "dcn_ranking":                  # 3.DCN/ModelManager.py:69-71 (type: 'vec' | 'matrix')
             p = dict(model_params)
             p.setdefault("categorical_features", self.feature_names)

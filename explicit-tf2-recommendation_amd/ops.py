@@ -155,6 +155,12 @@ class DedupPlan:
 
     def segment_sum(self, vals, E, row_div=1):
         """vals [n/row_div, E] -> [n, E]; rows >= n_uniq are zero."""
+        if E > 256:      # wide rows (FFM's F*E): the kernel takes up to 256 columns at a time
+            out = torch.empty((max(self.n, 1), E), dtype=torch.float32, device=vals.device)
+            for c0 in range(0, E, 256):
+                c1 = min(E, c0 + 256)
+                out[:, c0:c1] = self.segment_sum(vals[:, c0:c1].contiguous(), c1 - c0, row_div)
+            return out
         out = torch.empty((max(self.n, 1), E), dtype=torch.float32, device=vals.device)
         ws = torch.empty(lib.rec_segment_sum_workspace_bytes(self.n, E) // 4, dtype=torch.float32, device=vals.device)
         check(lib.rec_segment_sum_f32(_ptr(_f32(vals, "vals")), E, _ptr(self.perm), _ptr(self.seg_start), self.n,
@@ -601,3 +607,28 @@ def batchnorm_bwd(g, xhat, rstd, gamma, training):
     check(lib.rec_batchnorm_bwd_f32(_ptr(g), _ptr(xhat), _ptr(rstd), B, N, _ptr(gamma), 1 if training else 0, _ptr(gx),
                                     _ptr(ggamma), _ptr(gbeta), _stream()), "rec_batchnorm_bwd_f32")
     return gx, ggamma, gbeta
+
+
+def ffm_fwd(v, w, bias, X, want_prob=False, oob=None):
+    """v [V,F,E] field-aware table, w [V,1], bias [1], X [B,F] -> z [B] (and prob [B])."""
+    _f32(v, "v"); _table(w, "w"); _f32(bias, "bias"); _i64(X, "X")
+    V, F, E = v.shape
+    B = X.shape[0]
+    if X.shape[1] != F:
+        raise ValueError("X has %d fields, the table %d" % (X.shape[1], F))
+    z = torch.empty(B, dtype=torch.float32, device=v.device)
+    prob = torch.empty(B, dtype=torch.float32, device=v.device) if want_prob else None
+    check(lib.rec_ffm_fwd_f32(_ptr(v), F * E, _ptr(w), w.stride(0), _ptr(bias), V, E, _ptr(X), B, F, _ptr(z), _ptr(prob),
+                              _ptr(oob), _stream()), "rec_ffm_fwd_f32")
+    return z, prob
+
+
+def ffm_bwd_rows(v, X, gz, plan):
+    """-> g_rows [B*F, F, E] aligned with plan.uniq_ids (zero beyond n_uniq)."""
+    _f32(v, "v"); _i64(X, "X"); _f32(gz, "gz")
+    V, F, E = v.shape
+    B = X.shape[0]
+    rows = torch.empty((max(B * F, 1), F, E), dtype=torch.float32, device=v.device)
+    check(lib.rec_ffm_bwd_rows_f32(_ptr(v), F * E, V, E, _ptr(X), B, F, _ptr(gz), _ptr(plan.perm), _ptr(plan.seg_start),
+                                   _ptr(plan.n_uniq), _ptr(rows), _stream()), "rec_ffm_bwd_rows_f32")
+    return rows

@@ -342,6 +342,19 @@ int rec_ip_attn_bwd_f32(const float* embed, int64_t ld, int64_t V, int E, int C,
                         const float* q, int64_t ld_q, int64_t padding_index, const float* scores, const float* gpooled,
                         int64_t ld_gpooled, float* gkeys, float* gq, void* stream);
 
+/* ---- FFM, field-aware second order (FieldAwareInteractionLayer 2.FM/CustomLayers.py:428-462; FFMRankingLayer.call
+ * :398-425 computes the same numbers from F separate tables).  v [V, F, E] with row stride ld_v >= F*E floats:
+ * v[id, c, :] is the vector id uses against field c (table c of the loop form, row id).
+ *   z[b] = bias + sum_a w[X[b,a]] + sum_{a<c} < v[X[b,a], c, :], v[X[b,c], a, :] >,  prob = sigmoid(z). */
+int rec_ffm_fwd_f32(const float* v, int64_t ld_v, const float* w, int64_t ld_w, const float* bias, int64_t V, int E,
+                    const int64_t* X, int64_t B, int F, float* z, float* prob, int* oob_flag, void* stream);
+/* de-duplicated gradient rows of v on the plan of rec_dedup_plan_i64 over X (n = B*F):
+ *   g_rows[u, c, :] = sum over the lookups (b,a) of unique id u of gz[b] * v[X[b,c], a, :]  (c != a);  rows >= n_uniq
+ * are zero.  g_rows [B*F, F*E]. */
+int rec_ffm_bwd_rows_f32(const float* v, int64_t ld_v, int64_t V, int E, const int64_t* X, int64_t B, int F,
+                         const float* gz, const int32_t* perm, const int32_t* seg_start, const int64_t* n_uniq,
+                         float* g_rows, void* stream);
+
 /* ---- tf.keras.layers.BatchNormalization on [B,N] (3.DCN/CustomLayers.py:466,504; 2.FM/CustomLayers.py:69,78-79).
  * training != 0: batch mean / biased batch variance, moving statistics updated in place with `momentum`;
  * training == 0: moving statistics.  xhat [B,N] and rstd [N] are saved for the backward (may be NULL at inference).

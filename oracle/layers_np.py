@@ -628,3 +628,31 @@ def ip_attention_backward(table, q, series, gpooled, padding_index=0, dt=np.floa
     gq = np.einsum("bl,ble->be", gs, k)
     gkeys = scores[:, :, None] * gpooled[:, None, :] + gs[:, :, None] * q[:, None, :]
     return gkeys.astype(dt), gq.astype(dt)
+
+
+def ffm_forward(v, w, bias, X, dt=np.float32):
+    """FFMRankingLayer.call written as its double loop (2.FM/CustomLayers.py:398-425) over F tables
+    table_i = v[:, i, :]:  ebd_out[i][:, j] * ebd_out[j][:, i] = table_i[x_j] * table_j[x_i].  -> (prob, z) [B,1]."""
+    V, F, E = v.shape
+    v = v.astype(dt)
+    first = w[X, 0].astype(dt).sum(axis=1, keepdims=True)
+    second = np.zeros((X.shape[0], 1), dt)
+    for i in range(F):
+        for j in range(i + 1, F):
+            second[:, 0] += (v[X[:, j], i, :] * v[X[:, i], j, :]).sum(axis=1)
+    z = bias.astype(dt) + first + second
+    return sigmoid(z), z
+
+
+def ffm_backward(v, X, gz, dt=np.float32):
+    """Per-lookup gradient rows of v for an upstream d loss / d z = gz [B,1]: rows [B*F, F, E] where
+    rows[b*F + a, c, :] = gz[b] * v[X[b,c], a, :] (c != a); d w rows [B*F,1] = gz; d bias = sum gz."""
+    V, F, E = v.shape
+    B = X.shape[0]
+    v = v.astype(dt)
+    rows = np.zeros((B, F, F, E), dt)
+    for a in range(F):
+        for c in range(F):
+            if a != c:
+                rows[:, a, c, :] = gz.astype(dt) * v[X[:, c], a, :]
+    return rows.reshape(B * F, F, E), np.repeat(gz.astype(dt), F, axis=0), gz.astype(dt).sum(axis=0)

@@ -298,3 +298,25 @@ def gsu_combined(p, item_ids, series, padding_index=0, sparse=False):
     q = q.reshape(q.shape[0], -1)
     _, pooled = ip_attention(p["embed"], q, series, padding_index, sparse)
     return torch.cat([q, pooled], dim=1)
+
+
+def field_aware_interaction(v, X, sparse=False):
+    """FieldAwareInteractionLayer.call (2.FM/CustomLayers.py:436-462): embedding_lookup -> [B,F,F,E], multiply with
+    its transpose over the two field axes, keep the strict upper triangle -> [B, F(F-1)/2, E]."""
+    B, Fn = X.shape
+    V, _, E = v.shape
+    emb = lookup(v.reshape(V, Fn * E), X, sparse).reshape(B, Fn, Fn, E)
+    inter = emb * emb.transpose(1, 2)
+    mask = torch.triu(torch.ones(Fn, Fn), diagonal=1) > 0
+    return inter[:, mask, :]
+
+
+def ffm_logit(p, X, sparse=False):
+    """FFMLayer.call (:480-494).  p: v [V,F,E], w [V,1], bias [1]."""
+    linear = lookup(p["w"], X, sparse).sum(dim=1)
+    inter = field_aware_interaction(p["v"], X, sparse).sum(dim=1).sum(dim=1, keepdim=True)
+    return p["bias"] + linear + inter
+
+
+def ffm_forward(p, X, sparse=False):
+    return torch.sigmoid(ffm_logit(p, X, sparse))

@@ -320,3 +320,96 @@ def test_gsu_layer(R):
     (torch.cat([qd, pooled], dim=1) * dev(g)).sum().backward()
     (xc * torch.from_numpy(g).double()).sum().backward()
     assert close(layer.embed.embeddings.grad.to_dense().cpu().numpy(), tt.grad.numpy())
+
+
+# ------------------------------------------------------------------------------------------------
+# FFM
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,F,E,zipf", [(1, 1, 4, False), (4, 3, 4, False), (33, 5, 16, False), (700, 26, 16, False),
+                                        (65, 7, 6, False), (500, 10, 8, True)])
+def test_ffm_fwd_bwd(R, B, F, E, zipf):
+    ops = R.ops
+    V = 900
+    r = H.rng(B + F * 3)
+    v = (r.normal(size=(V, F, E)) * 0.2).astype(np.float32)
+    w = r.normal(size=(V, 1)).astype(np.float32)
+    bias = np.array([0.3], np.float32)
+    X = (np.minimum(r.zipf(1.3, size=(B, F)) - 1, V - 1) if zipf else r.integers(0, V, size=(B, F))).astype(np.int64)
+    z, prob = ops.ffm_fwd(dev(v), dev(w), dev(bias), dev(X), want_prob=True)
+    pn, zn = L.ffm_forward(v, w, bias, X, np.float64)
+    assert close(z.cpu().numpy(), zn[:, 0], 1e-5)
+    assert np.abs(prob.cpu().numpy() - pn[:, 0]).max() <= 1e-5
+    gz = r.normal(size=(B, 1)).astype(np.float32)
+    plan = ops.DedupPlan(dev(X), V)
+    rows = ops.ffm_bwd_rows(dev(v), dev(X), dev(gz[:, 0].copy()), plan)
+    nu = int(plan.n_uniq.item())
+    ref_rows, _, _ = L.ffm_backward(v, X, gz, np.float64)
+    uid, ref = L.dedup_indexed_slices(X.reshape(-1), ref_rows.reshape(B * F, F * E), "sorted")
+    assert nu == len(uid) and np.array_equal(plan.uniq_ids[:nu].cpu().numpy(), uid)
+    assert close(rows[:nu].reshape(nu, F * E).cpu().numpy(), ref)
+    assert torch.all(rows[nu:] == 0)
+
+
+def test_ffm_layers(R):
+    """FFMRankingLayer docstring inputs (2.FM/CustomLayers.py:372-374) and FFMLayer's default field list."""
+    names3 = ["item_tag1", "item_tag2", "item_tag3"]
+    ins = {"item_tag1": np.array([0, 1, 2, 3]), "item_tag2": np.array([4, 5, 6, 7]), "item_tag3": np.array([8, 9, 10, 11])}
+    layer = R.layers.FFMRankingLayer(feature_names=names3, feature_dims=20, embedding_dims=16).cuda()
+    out = layer({k: dev(v) for k, v in ins.items()})["output"]
+    p = {k: q.detach().cpu().numpy() for k, q in layer.named_parameters()}
+    assert set(p) == {"bias", "w", "fa_interaction_layer.v"}
+    assert len(layer.embedding_list) == 3 and tuple(layer.embedding_list[1].shape) == (20, 16)
+    X = L.index_assemble(ins, names3)
+    pn, _ = L.ffm_forward(p["fa_interaction_layer.v"], p["w"], p["bias"], X, np.float64)
+    assert tuple(out.shape) == (4, 1) and np.abs(out.detach().cpu().numpy() - pn).max() <= 1e-6
+    # a training step's gradients against the torch twin (vectorised FieldAwareInteractionLayer form)
+    names5 = ["item_tag1", "item_tag2", "item_tag3", "user_tag0", "user_tag1"]
+    V, E, B = 300, 8, 64
+    layer = R.layers.FFMLayer(feature_names=names5, feature_dims=V, embedding_dims=E).cuda()
+    r = H.rng(77)
+    with torch.no_grad():
+        layer.fa_interaction_layer.v.mul_(6.0)
+    ins = {n: r.integers(0, V, size=(B, 1)).astype(np.int64) for n in names5}
+    out = layer({k: dev(v) for k, v in ins.items()})["output"]
+    tp = {"v": layer.fa_interaction_layer.v.detach().cpu().double().requires_grad_(True),
+          "w": layer.w.detach().cpu().double().requires_grad_(True),
+          "bias": layer.bias.detach().cpu().double().requires_grad_(True)}
+    X = L.index_assemble(ins, names5)
+    o64 = T.ffm_forward(tp, torch.from_numpy(X))
+    assert np.abs(out.detach().cpu().numpy() - o64.detach().numpy()).max() <= 1e-5
+    y = (r.uniform(size=(B, 1)) < 0.3).astype(np.float32)
+    loss = R.functional.KerasBCE.apply(out, dev(y))
+    loss.backward()
+    lt = T.keras_bce(torch.from_numpy(y).double(), o64)
+    lt.backward()
+    assert abs(loss.item() - lt.item()) <= 1e-5
+    assert close(layer.fa_interaction_layer.v.grad.to_dense().cpu().numpy(), tp["v"].grad.numpy())
+    assert close(layer.w.grad.to_dense().cpu().numpy(), tp["w"].grad.numpy())
+    assert close(layer.bias.grad.cpu().numpy(), tp["bias"].grad.numpy())
+
+
+def test_f4_layers_train_through_manager(R):
+    """make_layer_choice strings of the reference (2.FM/ModelManager.py:76-82; 3.DCN/ModelManager.py:78-79): a few Adam
+    steps on one batch lower its loss."""
+    from explicit_tf2_recommendation_amd import data, layers
+    from explicit_tf2_recommendation_amd.model_manager import ModelManager
+    names = ["user_tag1", "user_tag2", "item_tag1", "item_tag2", "item_tag3"]
+    B, V = 128, 3000
+    for name, cls in (("ffm_ranking", layers.FFMRankingLayer), ("pnn_ranking", layers.PNNRankingLayer)):
+        layers.set_init_seed(5)
+        mm = ModelManager(feature_names=names, data_info=data.data_info(V, 5), embedding_dims=8, lr=0.01, batch=B,
+                          layer=name)
+        assert isinstance(mm.layer, cls)
+        batch = data.SyntheticGenerator(names, V, dist="zipf", seed=1).batch(B)
+        losses = [mm.train_loop(dict(batch)).item() for _ in range(8)]
+        assert np.all(np.isfinite(losses)) and losses[-1] < losses[0], (name, losses)
+    cat = ["uid", "iid", "utag1", "utag2", "utag3", "utag4", "itag1", "itag2", "itag3", "itag4"]
+    cont = ["itag4_origin", "itag4_square", "itag4_cube"]
+    layers.set_init_seed(6)
+    mm = ModelManager(feature_names=cat, continuous_features=cont, data_info=data.data_info(4000, 10), embedding_dims=8,
+                      lr=0.01, batch=B, layer="NFM")
+    assert isinstance(mm.layer, layers.NeuralFactorizationMachineLayer)
+    batch = data.SyntheticGenerator(cat, 4000, continuous=cont, seed=2).batch(B)
+    losses = [mm.train_loop(dict(batch)).item() for _ in range(8)]
+    assert np.all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert not torch.equal(mm.layer.bn_layer.moving_mean, torch.zeros_like(mm.layer.bn_layer.moving_mean))

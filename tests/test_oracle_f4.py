@@ -162,3 +162,56 @@ def test_ip_attention_hand_case():
     s, p = L.ip_attention_forward(tab, q, series, 0, np.float64)
     assert np.array_equal(s, [[4., 5., 0.]])                      # <q,k1> = 4, <q,k2> = 5, padded -> 0
     assert np.array_equal(p, [[4 * 1 + 5 * 3, 4 * 2 - 5]])
+
+
+def test_inner_product_network_docstring_case():
+    """InnerProductNetwork docstring input (2.FM/CustomLayers.py:603-606): arange(24).reshape(2,3,4); by hand."""
+    x = torch.arange(24, dtype=torch.float64).reshape(2, 3, 4)
+    out = T.ipn(x).numpy()
+    assert np.array_equal(out[0], [38., 62., 214.])              # <r0,r1>, <r0,r2>, <r1,r2>
+    assert np.array_equal(out[1], [12 * 16 + 13 * 17 + 14 * 18 + 15 * 19, 12 * 20 + 13 * 21 + 14 * 22 + 15 * 23,
+                                   16 * 20 + 17 * 21 + 18 * 22 + 19 * 23])
+
+
+@pytest.mark.parametrize("F,E", [(1, 4), (2, 3), (3, 16), (5, 8)])
+def test_ffm_np_loop_form_vs_torch_vectorised_form(F, E):
+    """The two forms the reference holds -- FFMRankingLayer's double loop over F tables and FFMLayer's vectorised
+    FieldAwareInteractionLayer -- give the same numbers; the numpy oracle follows the first, the torch one the second."""
+    V, B = 60, 21
+    r = H.rng(F * 10 + E)
+    v = r.normal(size=(V, F, E)).astype(np.float32) * 0.3
+    w = r.normal(size=(V, 1)).astype(np.float32)
+    bias = np.array([0.3], np.float32)
+    X = _ids(3, B, F, V)
+    tp = H.to_torch({"v": v, "w": w, "bias": bias}, torch.float64, True)
+    z_t = T.ffm_logit(tp, torch.from_numpy(X))
+    prob, z = L.ffm_forward(v, w, bias, X, np.float64)
+    assert np.abs(z - z_t.detach().numpy()).max() < 1e-12
+    assert np.abs(prob - T.ffm_forward(tp, torch.from_numpy(X)).detach().numpy()).max() < 1e-12
+    gz = r.normal(size=(B, 1))
+    (z_t * torch.from_numpy(gz)).sum().backward()
+    rows, wrows, gb = L.ffm_backward(v, X, gz, np.float64)
+    dense = np.zeros((V, F, E))
+    np.add.at(dense, X.reshape(-1), rows)
+    assert np.abs(dense - tp["v"].grad.numpy()).max() < 1e-12
+    dw = np.zeros((V, 1))
+    np.add.at(dw, X.reshape(-1), wrows)
+    assert np.abs(dw - tp["w"].grad.numpy()).max() < 1e-12
+    assert np.abs(gb - tp["bias"].grad.numpy()).max() < 1e-12
+
+
+def test_ffm_docstring_micro_case():
+    """FFMRankingLayer docstring inputs (2.FM/CustomLayers.py:372-374), hand-checkable tables, expected by hand."""
+    ins = {"item_tag1": np.array([0, 1, 2, 3]), "item_tag2": np.array([4, 5, 6, 7]), "item_tag3": np.array([8, 9, 10, 11])}
+    X = L.index_assemble(ins, ["item_tag1", "item_tag2", "item_tag3"])
+    V, F, E = 20, 3, 4
+    v = H.det_table(V, F * E).reshape(V, F, E)
+    w = H.det_table(V, 1)
+    bias = np.array([0.25], np.float32)
+    prob, z = L.ffm_forward(v, w, bias, X, np.float64)
+    for b in range(4):
+        x = X[b]
+        zz = 0.25 + sum(float(w[x[f], 0]) for f in range(3))
+        zz += float(v[x[0], 1].astype(np.float64) @ v[x[1], 0]) + float(v[x[0], 2].astype(np.float64) @ v[x[2], 0]) \
+            + float(v[x[1], 2].astype(np.float64) @ v[x[2], 1])
+        assert abs(z[b, 0] - zz) < 1e-12
