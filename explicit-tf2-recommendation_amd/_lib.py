@@ -54,8 +54,9 @@ SIGNATURES = {
     "rec_ip_attn_bwd_f32": (i32, [p, i64, i64, i32, i32, p, i64, i32, p, i64, i64, p, p, i64, p, p, p]),
     "rec_ffm_fwd_f32": (i32, [p, i64, p, i64, p, i64, i32, p, i64, i32, p, p, p, p]),
     "rec_ffm_bwd_rows_f32": (i32, [p, i64, i64, i32, p, i64, i32, p, p, p, p, p, p]),
-    "rec_batchnorm_fwd_f32": (i32, [p, i64, i64, i32, p, p, f32, f32, i32, p, p, p, p, p, p]),
-    "rec_batchnorm_bwd_f32": (i32, [p, p, p, i64, i32, p, i32, p, p, p, p]),
+    "rec_batchnorm_workspace_bytes": (sz, [i64, i32]),
+    "rec_batchnorm_fwd_f32": (i32, [p, i64, i64, i32, p, p, f32, f32, i32, p, p, p, p, p, p, p]),
+    "rec_batchnorm_bwd_f32": (i32, [p, p, p, i64, i32, p, i32, p, p, p, p, p]),
     "rec_shard_bucketize_workspace_bytes": (sz, [i64, i32]),
     "rec_shard_bucketize_i64": (i32, [p, i64, i64, i32, p, p, p, p, p, sz, p]),
     "rec_colsort_shard_map_i64": (i32, [p, p, p, p, i64, i32, i64, i32, p, p, p, p, p, p]),

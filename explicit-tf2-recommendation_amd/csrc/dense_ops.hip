@@ -743,103 +743,237 @@ extern "C" int rec_l2_rows_f32(const float* table, int64_t ld, int64_t V, int E,
 // tf.keras.layers.BatchNormalization on [B,N] (axis=-1, non-fused path: biased batch variance for both the
 // normalisation and the moving average), as NFM applies it to [bi-interaction | continuous]
 // (3.DCN/CustomLayers.py:466,504) and MLPLayer(is_batch_norm=True) after BiasAdd (2.FM/CustomLayers.py:78-79).
-// N is a layer width (tens), B the batch: one workgroup per column, two passes for the moments like tf.nn.moments
-// (mean first, then mean of squared differences), deterministic tree sums.
+// N is a layer width (tens), B the batch, so the batch axis carries the parallelism: slabs of BN_ROWS rows produce
+// per-column (mean, M2) partials (two passes over registers, like tf.nn.moments), one small workgroup merges them
+// in a fixed order (Chan's parallel-variance update: no E[x^2]-E[x]^2 cancellation), the normalisation is
+// elementwise.  Deterministic; workspace = rec_batchnorm_workspace_bytes(B, N).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float block_sum_1024(float v, float* red) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  __syncthreads();                                          // red[] may still be read from the previous call
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float s = 0.f;
-#pragma unroll
-  for (int w = 0; w < 16; ++w) s += red[w];
-  return s;
+#define BN_RPT 8      // rows per thread
+
+__host__ __device__ static inline int bn_cols_pow2(int N) {
+  int p = 1;
+  while (p < N && p < 256) p <<= 1;
+  return p;
 }
 
-__global__ __launch_bounds__(1024) void batchnorm_fwd_kernel(const float* __restrict__ x, int64_t ld_x, int64_t B, int N,
-                                                             const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, float eps, float momentum,
-                                                             int training, float* __restrict__ moving_mean,
-                                                             float* __restrict__ moving_var, float* __restrict__ y,
-                                                             float* __restrict__ xhat, float* __restrict__ rstd_out) {
-  __shared__ float red[16];
-  const int n = blockIdx.x;
+// merge (n_b, mean_b, M2_b) into (n, mean, M2)
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& M2, float nb, float meanb, float M2b) {
+  if (nb == 0.f) return;
+  float nt = n + nb;
+  float d = meanb - mean;
+  mean += d * (nb / nt);
+  M2 += M2b + d * d * (n * nb / nt);
+  n = nt;
+}
+
+// grid (slabs, column tiles); thread = (row slot rs, column c) with NP = power of two >= min(N,256) columns per tile
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int64_t ld_x, int64_t B, int N,
+                                                         int NP, float* __restrict__ part) {
+  __shared__ float sm[3][256];
+  const int RS = 256 / NP;
+  const int c = threadIdx.x % NP, rs = threadIdx.x / NP;
+  const int col = blockIdx.y * NP + c;
+  const int64_t r0 = (int64_t)blockIdx.x * RS * BN_RPT;
+  float v[BN_RPT];
+  float n = 0.f, s = 0.f;
+#pragma unroll
+  for (int k = 0; k < BN_RPT; ++k) {
+    int64_t r = r0 + rs + (int64_t)k * RS;
+    bool in = r < B && col < N;
+    v[k] = in ? x[r * ld_x + col] : 0.f;
+    if (in) { n += 1.f; s += v[k]; }
+  }
+  float mean = n > 0.f ? s / n : 0.f, M2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < BN_RPT; ++k) {
+    int64_t r = r0 + rs + (int64_t)k * RS;
+    if (r < B && col < N) { float d = v[k] - mean; M2 += d * d; }
+  }
+  sm[0][threadIdx.x] = n; sm[1][threadIdx.x] = mean; sm[2][threadIdx.x] = M2;
+  __syncthreads();
+  if (rs == 0 && col < N) {
+    for (int q = 1; q < RS; ++q) chan_merge(n, mean, M2, sm[0][q * NP + c], sm[1][q * NP + c], sm[2][q * NP + c]);
+    float* o = part + ((int64_t)blockIdx.x * N + col) * 3;
+    o[0] = n; o[1] = mean; o[2] = M2;
+  }
+}
+
+// one workgroup per column: merge the slab partials (fixed order: strided per thread, then a tree over threads)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ part, int n_slabs, int N, float eps,
+                                                       float momentum, int training, float* __restrict__ moving_mean,
+                                                       float* __restrict__ moving_var, float* __restrict__ stats) {
+  __shared__ float sm[3][256];
+  const int col = blockIdx.x;
   float mean, var;
   if (training) {
-    float s = 0.f;
-    for (int64_t b = threadIdx.x; b < B; b += 1024) s += x[b * ld_x + n];
-    mean = block_sum_1024(s, red) / (float)B;
-    float q = 0.f;
-    for (int64_t b = threadIdx.x; b < B; b += 1024) {
-      float d = x[b * ld_x + n] - mean;
-      q += d * d;
+    float n = 0.f, m = 0.f, M2 = 0.f;
+    for (int sidx = threadIdx.x; sidx < n_slabs; sidx += 256) {
+      const float* p = part + ((int64_t)sidx * N + col) * 3;
+      chan_merge(n, m, M2, p[0], p[1], p[2]);
     }
-    var = block_sum_1024(q, red) / (float)B;
+    sm[0][threadIdx.x] = n; sm[1][threadIdx.x] = m; sm[2][threadIdx.x] = M2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) {
+        chan_merge(n, m, M2, sm[0][threadIdx.x + o], sm[1][threadIdx.x + o], sm[2][threadIdx.x + o]);
+        sm[0][threadIdx.x] = n; sm[1][threadIdx.x] = m; sm[2][threadIdx.x] = M2;
+      }
+      __syncthreads();
+    }
+    mean = sm[1][0];
+    var = sm[2][0] / sm[0][0];
     if (threadIdx.x == 0) {
-      moving_mean[n] = moving_mean[n] * momentum + mean * (1.f - momentum);
-      moving_var[n] = moving_var[n] * momentum + var * (1.f - momentum);
+      moving_mean[col] = moving_mean[col] * momentum + mean * (1.f - momentum);
+      moving_var[col] = moving_var[col] * momentum + var * (1.f - momentum);
     }
   } else {
-    mean = moving_mean[n];
-    var = moving_var[n];
+    mean = moving_mean[col];
+    var = moving_var[col];
   }
-  const float rstd = 1.0f / sqrtf(var + eps);
-  const float ga = gamma ? gamma[n] : 1.f, be = beta ? beta[n] : 0.f;
-  if (threadIdx.x == 0 && rstd_out) rstd_out[n] = rstd;
-  for (int64_t b = threadIdx.x; b < B; b += 1024) {
-    float h = (x[b * ld_x + n] - mean) * rstd;
-    if (xhat) xhat[b * N + n] = h;
-    y[b * N + n] = h * ga + be;
+  if (threadIdx.x == 0) {
+    stats[col] = mean;
+    stats[N + col] = 1.0f / sqrtf(var + eps);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int64_t ld_x, int64_t B, int N,
+                                                       const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ y, float* __restrict__ xhat,
+                                                       float* __restrict__ rstd_out) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < N && rstd_out) rstd_out[t] = stats[N + t];
+  if (t >= B * N) return;
+  int64_t r = t / N;
+  int c = (int)(t - r * N);
+  float h = (x[r * ld_x + c] - stats[c]) * stats[N + c];
+  if (xhat) xhat[t] = h;
+  y[t] = h * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
+}
+
+// backward partials: per slab and column  sum g  and  sum g*xhat
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ g, const float* __restrict__ xhat,
+                                                             int64_t B, int N, int NP, float* __restrict__ part) {
+  __shared__ float sm[2][256];
+  const int RS = 256 / NP;
+  const int c = threadIdx.x % NP, rs = threadIdx.x / NP;
+  const int col = blockIdx.y * NP + c;
+  const int64_t r0 = (int64_t)blockIdx.x * RS * BN_RPT;
+  float s = 0.f, sh = 0.f;
+#pragma unroll
+  for (int k = 0; k < BN_RPT; ++k) {
+    int64_t r = r0 + rs + (int64_t)k * RS;
+    if (r < B && col < N) {
+      float gv = g[r * N + col];
+      s += gv;
+      sh += gv * xhat[r * N + col];
+    }
+  }
+  sm[0][threadIdx.x] = s; sm[1][threadIdx.x] = sh;
+  __syncthreads();
+  if (rs == 0 && col < N) {
+    for (int q = 1; q < RS; ++q) { s += sm[0][q * NP + c]; sh += sm[1][q * NP + c]; }
+    float* o = part + ((int64_t)blockIdx.x * N + col) * 2;
+    o[0] = s; o[1] = sh;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ part, int n_slabs, int N,
+                                                           float* __restrict__ ggamma, float* __restrict__ gbeta,
+                                                           float* __restrict__ sums) {
+  __shared__ float sm[2][256];
+  const int col = blockIdx.x;
+  float s = 0.f, sh = 0.f;
+  for (int sidx = threadIdx.x; sidx < n_slabs; sidx += 256) {
+    const float* p = part + ((int64_t)sidx * N + col) * 2;
+    s += p[0];
+    sh += p[1];
+  }
+  sm[0][threadIdx.x] = s; sm[1][threadIdx.x] = sh;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      sm[0][threadIdx.x] += sm[0][threadIdx.x + o];
+      sm[1][threadIdx.x] += sm[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    sums[col] = sm[0][0];
+    sums[N + col] = sm[1][0];
+    if (gbeta) gbeta[col] = sm[0][0];
+    if (ggamma) ggamma[col] = sm[1][0];
   }
 }
 
 // training: gx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat));  inference: gx = gamma*rstd*g
-__global__ __launch_bounds__(1024) void batchnorm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ xhat,
-                                                             const float* __restrict__ rstd, int64_t B, int N,
-                                                             const float* __restrict__ gamma, int training,
-                                                             float* __restrict__ gx, float* __restrict__ ggamma,
-                                                             float* __restrict__ gbeta) {
-  __shared__ float red[16];
-  const int n = blockIdx.x;
-  float s = 0.f, sh = 0.f;
-  for (int64_t b = threadIdx.x; b < B; b += 1024) {
-    float gv = g[b * N + n];
-    s += gv;
-    sh += gv * xhat[b * N + n];
-  }
-  s = block_sum_1024(s, red);
-  sh = block_sum_1024(sh, red);
-  if (threadIdx.x == 0) {
-    if (gbeta) gbeta[n] = s;
-    if (ggamma) ggamma[n] = sh;
-  }
-  const float k = (gamma ? gamma[n] : 1.f) * rstd[n];
-  const float ms = training ? s / (float)B : 0.f, msh = training ? sh / (float)B : 0.f;
-  for (int64_t b = threadIdx.x; b < B; b += 1024) gx[b * N + n] = k * (g[b * N + n] - ms - xhat[b * N + n] * msh);
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ xhat,
+                                                           const float* __restrict__ rstd, int64_t B, int N,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ sums, int training,
+                                                           float* __restrict__ gx) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= B * N) return;
+  int c = (int)(t % N);
+  float k = (gamma ? gamma[c] : 1.f) * rstd[c];
+  float ms = training ? sums[c] / (float)B : 0.f, msh = training ? sums[N + c] / (float)B : 0.f;
+  gx[t] = k * (g[t] - ms - xhat[t] * msh);
+}
+
+static inline int64_t bn_slabs(int64_t B, int N) {
+  int rs = 256 / bn_cols_pow2(N);
+  return ceil_div64(B, (int64_t)rs * BN_RPT);
+}
+
+extern "C" size_t rec_batchnorm_workspace_bytes(int64_t B, int N) {
+  if (B <= 0 || N <= 0) return 256;
+  return sizeof(float) * ((size_t)bn_slabs(B, N) * N * 3 + 2 * (size_t)N) + 256;
 }
 
 extern "C" int rec_batchnorm_fwd_f32(const float* x, int64_t ld_x, int64_t B, int N, const float* gamma,
                                      const float* beta, float eps, float momentum, int training, float* moving_mean,
-                                     float* moving_var, float* y, float* xhat, float* rstd, void* stream) {
+                                     float* moving_var, float* y, float* xhat, float* rstd, void* workspace,
+                                     void* stream) {
   if (B < 0 || N <= 0 || ld_x < N) return REC_E_ARG;
   if (B == 0) return REC_OK;
-  if (!x || !moving_mean || !moving_var || !y) return REC_E_ARG;
-  hipLaunchKernelGGL(batchnorm_fwd_kernel, dim3((unsigned)N), dim3(1024), 0, as_stream(stream), x, ld_x, B, N, gamma,
-                     beta, eps, momentum, training, moving_mean, moving_var, y, xhat, rstd);
+  if (!x || !moving_mean || !moving_var || !y || !workspace) return REC_E_ARG;
+  hipStream_t st = as_stream(stream);
+  const int NP = bn_cols_pow2(N);
+  const int64_t slabs = bn_slabs(B, N);
+  float* part = static_cast<float*>(workspace);
+  float* stats = part + slabs * N * 3;
+  if (training) {
+    hipLaunchKernelGGL(bn_partial_kernel, dim3((unsigned)slabs, (unsigned)((N + NP - 1) / NP)), dim3(256), 0, st, x,
+                       ld_x, B, N, NP, part);
+    REC_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)N), dim3(256), 0, st, part, (int)slabs, N, eps, momentum, training,
+                     moving_mean, moving_var, stats);
+  REC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div64(B * N, 256)), dim3(256), 0, st, x, ld_x, B, N, stats,
+                     gamma, beta, y, xhat, rstd);
   REC_LAUNCH_CHECK();
   return REC_OK;
 }
 
 extern "C" int rec_batchnorm_bwd_f32(const float* g, const float* xhat, const float* rstd, int64_t B, int N,
                                      const float* gamma, int training, float* gx, float* ggamma, float* gbeta,
-                                     void* stream) {
+                                     void* workspace, void* stream) {
   if (B < 0 || N <= 0) return REC_E_ARG;
   if (B == 0) return REC_OK;
-  if (!g || !xhat || !rstd || !gx) return REC_E_ARG;
-  hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3((unsigned)N), dim3(1024), 0, as_stream(stream), g, xhat, rstd, B, N,
-                     gamma, training, gx, ggamma, gbeta);
+  if (!g || !xhat || !rstd || !gx || !workspace) return REC_E_ARG;
+  hipStream_t st = as_stream(stream);
+  const int NP = bn_cols_pow2(N);
+  const int64_t slabs = bn_slabs(B, N);
+  float* part = static_cast<float*>(workspace);
+  float* sums = part + slabs * N * 3;
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((unsigned)slabs, (unsigned)((N + NP - 1) / NP)), dim3(256), 0, st, g,
+                     xhat, B, N, NP, part);
+  REC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((unsigned)N), dim3(256), 0, st, part, (int)slabs, N, ggamma, gbeta, sums);
+  REC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ceil_div64(B * N, 256)), dim3(256), 0, st, g, xhat, rstd, B, N,
+                     gamma, sums, training, gx);
   REC_LAUNCH_CHECK();
   return REC_OK;
 }

@@ -98,6 +98,71 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int64_t M, int64_t N, int
   }
 }
 
+// ---- tall-skinny variant: N <= 64 (MLP layers of width 32, 8, 2, 1: every `units` list of the reference), A and B
+// row-major.  With a single column of tiles no A element is shared between waves, so nothing is staged: lane
+// (row, h) reads its 8 consecutive k values of A straight into registers and the matching B values (128-byte
+// coalesced, L2-resident) -- the MFMA only needs both operands to agree on which k sits in which slot.  No LDS, no
+// barrier in the K loop; the 4 waves of a workgroup split K (the 64x64 kernel ran 47 dependent load->barrier->MFMA
+// rounds on 128 workgroups for [8192,741]x[741,32]: ~100 us) and add their partials in wave order.
+template <int NT>
+__global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(int64_t M, int64_t N, int64_t K,
+                                                              const float* __restrict__ A, int64_t lda,
+                                                              const float* __restrict__ B, int64_t ldb,
+                                                              float* __restrict__ C, int64_t ldc, int epi,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ e0, int64_t lde0,
+                                                              const float* __restrict__ e1, int64_t lde1,
+                                                              float* __restrict__ aux) {
+  __shared__ float part[4][32][32 * NT + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane & 31, h = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * 32;
+  const int64_t kper = ((((K + 15) >> 4) + 3) >> 2) << 4;          // 16-deep steps, split over the 4 waves
+  const int64_t k_begin = wave * kper;
+  const int64_t k_end = (k_begin + kper < K) ? k_begin + kper : K;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const bool rok = m0 + row < M;
+  const float* arow = A + (m0 + row) * lda;
+  for (int64_t k0 = k_begin; k0 < k_end; k0 += 32) {        // two 16-deep steps per round: 16 + 16*NT loads in flight
+    float a[2][8], b[2][NT][8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int64_t kb = k0 + 16 * c + 8 * h;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        bool kok = kb + s < k_end;
+        a[c][s] = (rok && kok) ? arow[kb + s] : 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          b[c][t][s] = (kok && 32 * t + row < N) ? B[(kb + s) * ldb + 32 * t + row] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s], b[c][t][s], acc[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * h][32 * t + row] = acc[t][r];
+  __syncthreads();
+  for (int e = tid; e < 32 * 32 * NT; e += 256) {
+    int r = e / (32 * NT), c = e - r * (32 * NT);
+    int64_t gm = m0 + r;
+    if (gm < M && c < N) {
+      float v = (part[0][r][c] + part[1][r][c]) + (part[2][r][c] + part[3][r][c]);
+      C[gm * ldc + c] = epilogue(epi, v, gm, c, bias, e0, lde0, e1, lde1, aux, ldc);
+    }
+  }
+}
+
 // ---- large-tile variant: 128x128x16 block tile, 4 waves as 2x2, each wave a 64x64 patch = 2x2 MFMA 32x32 tiles
 // (64 accumulator registers), the next K-tile prefetched into registers while the current one is multiplied (one
 // barrier pair per K-tile, global latency hidden behind 32 MFMAs per wave).  Used when both M and N are large
@@ -238,6 +303,17 @@ extern "C" int rec_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
   float* ws = split_k > 1 ? workspace : nullptr;
   hipStream_t st = as_stream(stream);
   const bool big = M > 64 && N > 64;
+  if (!transA && !transB && N <= 64 && M >= 256 && split_k == 1) {
+    dim3 grid((unsigned)ceil_div64(M, 32));
+    if (N <= 32)
+      hipLaunchKernelGGL((gemm_f32_skinny_kernel<1>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc,
+                         epilogue_kind, bias, e0, lde0, e1, lde1, aux);
+    else
+      hipLaunchKernelGGL((gemm_f32_skinny_kernel<2>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc,
+                         epilogue_kind, bias, e0, lde0, e1, lde1, aux);
+    REC_LAUNCH_CHECK();
+    return REC_OK;
+  }
   if (big) {
     dim3 grid((unsigned)ceil_div64(M, LM), (unsigned)ceil_div64(N, LN), (unsigned)split_k);
     if (grid.y > 65535u) return REC_E_UNSUPPORTED;

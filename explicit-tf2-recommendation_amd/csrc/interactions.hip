@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void emb_ipn_fwd_kernel(const float* __restric
                                                           int64_t ld, const int64_t* __restrict__ X, int64_t B, int F,
                                                           int EX, int vec4, float* __restrict__ out, int64_t ld_out, int* oob) {
   extern __shared__ float ipn_lds[];
-  const int ES = E + 1, P = F * (F - 1) / 2, W = F * E + P;
+  const int ES = vec4 ? E + 4 : E + 1, P = F * (F - 1) / 2, W = F * E + P;
   float* rows = ipn_lds;                                    // [EX][F][ES]
   int* ids = reinterpret_cast<int*>(rows + EX * F * ES);    // [EX][F]
   unsigned char* pi = reinterpret_cast<unsigned char*>(ids + EX * F);   // [P]
@@ -42,21 +42,51 @@ __global__ __launch_bounds__(256) void emb_ipn_fwd_kernel(const float* __restric
     for (int j = i + 1; j < F; ++j, ++p) { pi[p] = (unsigned char)i; pj[p] = (unsigned char)j; }
   }
   __syncthreads();
+  // every lane issues its (up to 4) row loads back to back before the first one is consumed: at this size the kernel
+  // is a handful of dependent memory round trips, so the loads of a lane must not wait for each other
   if (vec4) {
-    const int E4 = E >> 2;
-    for (int i = tid; i < n_ex * F * E4; i += 256) {
-      int r = i / E4, d4 = i - r * E4;
-      int id = ids[r];
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (id >= 0) v = *reinterpret_cast<const float4*>(table + (int64_t)id * ld + 4 * d4);
-      float* dst = rows + r * ES + 4 * d4;
-      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    const int E4 = E >> 2, total = n_ex * F * E4;
+    for (int i0 = tid; i0 < total; i0 += 4 * 256) {
+      float4 v[4];
+      int r[4], d4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int i = i0 + u * 256;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        r[u] = -1;
+        if (i < total) {
+          r[u] = i / E4;
+          d4[u] = i - r[u] * E4;
+          int id = ids[r[u]];
+          if (id >= 0) v[u] = *reinterpret_cast<const float4*>(table + (int64_t)id * ld + 4 * d4[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (r[u] < 0) continue;
+        *reinterpret_cast<float4*>(rows + r[u] * ES + 4 * d4[u]) = v[u];
+      }
     }
   } else {
-    for (int i = tid; i < n_ex * F * E; i += 256) {
-      int r = i / E, d = i - r * E;
-      int id = ids[r];
-      rows[r * ES + d] = (id >= 0) ? table[(int64_t)id * ld + d] : 0.f;
+    const int total = n_ex * F * E;
+    for (int i0 = tid; i0 < total; i0 += 4 * 256) {
+      float v[4];
+      int r[4], d[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int i = i0 + u * 256;
+        v[u] = 0.f;
+        r[u] = -1;
+        if (i < total) {
+          r[u] = i / E;
+          d[u] = i - r[u] * E;
+          int id = ids[r[u]];
+          if (id >= 0) v[u] = table[(int64_t)id * ld + d[u]];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r[u] >= 0) rows[r[u] * ES + d[u]] = v[u];
     }
   }
   __syncthreads();
@@ -67,13 +97,23 @@ __global__ __launch_bounds__(256) void emb_ipn_fwd_kernel(const float* __restric
       float v;
       if (k < F * E) {
         int f = k / E;
-        v = re[k + f];                                      // f*ES + d  with  k = f*E + d
+        v = re[k + f * (ES - E)];                           // f*ES + d  with  k = f*E + d
       } else {
         int p = k - F * E;
         const float* a = re + (int)pi[p] * ES;
         const float* c = re + (int)pj[p] * ES;
         v = 0.f;
-        for (int d = 0; d < E; ++d) v += a[d] * c[d];
+        if (vec4) {                                         // independent 16-byte LDS reads, 4 MACs each
+#pragma unroll 2
+          for (int d = 0; d < E; d += 4) {
+            float4 x = *reinterpret_cast<const float4*>(a + d);
+            float4 y = *reinterpret_cast<const float4*>(c + d);
+            v += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+          }
+        } else {
+#pragma unroll 4
+          for (int d = 0; d < E; ++d) v += a[d] * c[d];
+        }
       }
       o[k] = v;
     }
@@ -85,43 +125,69 @@ __global__ __launch_bounds__(256) void emb_ipn_bwd_kernel(const float* __restric
                                                           const float* __restrict__ g, int64_t ld_g, int64_t B, int F,
                                                           int E, int EX, float* __restrict__ vals) {
   extern __shared__ float ipn_lds[];
-  const int ES = E + 1, P = F * (F - 1) / 2, FE = F * E;
+  const int ES = E + 1, FE = F * E, GW = FE + F * F;
   float* rows = ipn_lds;                 // [EX][F][ES]
-  float* gp = rows + EX * F * ES;        // [EX][P]
-  const int tid = threadIdx.x;
+  float* gl = rows + EX * F * ES;        // [EX][GW]: the flat part of the gradient row, then G[i][j] = g_pair(i,j)
+  const int tid = threadIdx.x;           //           as a full symmetric F x F matrix with a zero diagonal
   const int64_t b0 = (int64_t)blockIdx.x * EX;
   const int n_ex = (B - b0 < EX) ? (int)(B - b0) : EX;
-  for (int ex = 0; ex < n_ex; ++ex) {
-    const float* o = out + (b0 + ex) * ld_out;
-    const float* gg = g + (b0 + ex) * ld_g;
-    for (int k = tid; k < FE; k += 256) rows[ex * F * ES + k + k / E] = o[k];
-    for (int p = tid; p < P; p += 256) gp[ex * P + p] = gg[FE + p];
+  // 8 independent loads per lane in flight (4 of `out`, 4 of `g`) -- see the forward kernel
+  const int total = n_ex * GW;
+  for (int i0 = tid; i0 < total; i0 += 4 * 256) {
+    float vo[4], vg[4];
+    int ex[4], k[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int i = i0 + u * 256;
+      ex[u] = -1;
+      vo[u] = vg[u] = 0.f;
+      if (i < total) {
+        ex[u] = i / GW;
+        k[u] = i - ex[u] * GW;
+        int src = k[u];
+        if (k[u] >= FE) {
+          int ij = k[u] - FE, ii = ij / F, jj = ij - ii * F;
+          src = ii == jj ? -1 : FE + (ii < jj ? pair_index(ii, jj, F) : pair_index(jj, ii, F));
+        } else {
+          vo[u] = out[(b0 + ex[u]) * ld_out + k[u]];
+        }
+        if (src >= 0) vg[u] = g[(b0 + ex[u]) * ld_g + src];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (ex[u] < 0) continue;
+      gl[ex[u] * GW + k[u]] = vg[u];
+      if (k[u] < FE) rows[ex[u] * F * ES + k[u] + k[u] / E] = vo[u];
+    }
   }
   __syncthreads();
   for (int ex = 0; ex < n_ex; ++ex) {
     const float* re = rows + ex * F * ES;
-    const float* gpe = gp + ex * P;
-    const float* gg = g + (b0 + ex) * ld_g;
+    const float* gg = gl + ex * GW;
     float* vo = vals + (b0 + ex) * (int64_t)FE;
     for (int k = tid; k < FE; k += 256) {
       int i = k / E, d = k - i * E;
+      const float* Gi = gg + FE + i * F;
       float acc = gg[k];
-      for (int j = 0; j < i; ++j) acc += gpe[pair_index(j, i, F)] * re[j * ES + d];
-      int p = pair_index(i, i + 1, F);
-      for (int j = i + 1; j < F; ++j, ++p) acc += gpe[p] * re[j * ES + d];
+#pragma unroll 8
+      for (int j = 0; j < F; ++j) acc += Gi[j] * re[j * ES + d];     // the diagonal entry is zero
       vo[k] = acc;
     }
   }
 }
 
+// Examples per workgroup.  A workgroup is load -> barrier -> compute -> store with nothing overlapped inside it, so
+// the overlap has to come from MANY resident workgroups per CU: keep the LDS of one at <= 16 KB (>= 8 per CU) and the
+// grid at >= 1024 workgroups; only a single example that needs more may take up to 64 KB.
 static int ipn_examples_per_group(int64_t B, int F, int E, bool bwd, size_t* lds) {
   const int P = F * (F - 1) / 2;
   int EX = 8;
-  while (EX > 1 && (B / EX) < 1024) EX >>= 1;              // >= 4 workgroups per CU before examples are grouped
+  while (EX > 1 && (B / EX) < 1024) EX >>= 1;
   for (;; EX >>= 1) {
-    size_t bytes = bwd ? (size_t)EX * ((size_t)F * (E + 1) + P) * 4
-                       : (size_t)EX * F * (E + 1) * 4 + (size_t)EX * F * 4 + 2 * (size_t)P + 16;
-    if (bytes <= 64 * 1024 || EX == 1) {
+    size_t bytes = bwd ? (size_t)EX * ((size_t)F * (E + 1) + (size_t)F * E + (size_t)F * F) * 4
+                       : (size_t)EX * F * (E + 4) * 4 + (size_t)EX * F * 4 + 2 * (size_t)P + 16;
+    if (bytes <= 16 * 1024 || EX == 1) {
       *lds = bytes;
       return (bytes <= 64 * 1024) ? EX : 0;
     }
@@ -279,8 +345,8 @@ extern "C" int rec_emb_bi_bwd_vals_f32(const float* table, int64_t V, int E, int
 // ------------------------------------------------------------------------------------------------
 // SIM GSU inner-product attention.  key k_t = concat_r embed[series[b,t,r]] (D = C*E), valid[b,t] = series[b,t,0] !=
 // padding_index;  scores[b,t] = valid * <q_b, k_t>;  pooled[b,:] = sum_t scores[b,t] * k_t.
-// One wave per example, lane l owns dims l, l+64, ...; TB time steps are in flight together; padded steps are never
-// read (their score and their gradient are zero by definition).
+// One workgroup per example, its 4 waves share the time axis; lane l owns dims l, l+64, ...; TB time steps are in
+// flight together per wave; padded steps are never read (their score and their gradient are zero by definition).
 // backward: gs_t = <gpooled, k_t>;  gq = sum_t valid*gs_t*k_t;  gkeys[b,t,:] = scores_t*gpooled + valid*gs_t*q.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum64(float v) {
@@ -297,23 +363,23 @@ __global__ __launch_bounds__(256) void ip_attn_kernel(const float* __restrict__ 
                                                       int64_t ld_p, const float* __restrict__ gpooled, int64_t ld_gp,
                                                       float* __restrict__ gkeys, float* __restrict__ gq, int* oob) {
   constexpr int TB = 8;
-  extern __shared__ int attn_ids[];                        // [4 waves][T*C]; -1 = out of range, -2 = padded step
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+  extern __shared__ int attn_ids[];                        // [T*C]; -1 = out of range, -2 = padded step
   const int D = C * E;
-  int* ids = attn_ids + wave * T * C;
+  float* partial = reinterpret_cast<float*>(attn_ids + T * C);       // [4 waves][D]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t b = blockIdx.x;
   bool bad = false;
-  for (int i = lane; i < T * C && b < B; i += 64) {
+  for (int i = threadIdx.x; i < T * C; i += 256) {
     int t = i / C;
     int64_t id = series[(b * T) * C + i];
     int64_t id0 = series[(b * T + t) * C];
     bool ok = (uint64_t)id < (uint64_t)V;
+    bool pad = id0 == padding_index;
     bad |= !ok;
-    ids[i] = (id0 == padding_index) ? -2 : (ok ? (int)id : -1);
+    attn_ids[i] = pad ? -2 : (ok ? (int)id : -1);
   }
   if (bad && oob) *oob = 1;
   __syncthreads();
-  if (b >= B) return;                                      // after the only barrier
   int rr[NPL], ee[NPL];
   float qv[NPL], gp[NPL], acc[NPL];
 #pragma unroll
@@ -326,19 +392,20 @@ __global__ __launch_bounds__(256) void ip_attn_kernel(const float* __restrict__ 
     gp[a] = (BWD && in) ? gpooled[b * ld_gp + d] : 0.f;
     acc[a] = 0.f;
   }
-  for (int t0 = 0; t0 < T; t0 += TB) {
+  // the 4 waves take the chunks of TB steps round-robin (padding sits at the tail of a series: interleaving keeps the
+  // waves balanced)
+  for (int t0 = wave * TB; t0 < T; t0 += 4 * TB) {
     float k[TB][NPL];
     bool valid[TB];
 #pragma unroll
     for (int u = 0; u < TB; ++u) {
       int t = t0 + u;
-      valid[u] = false;
+      valid[u] = t < T && attn_ids[t * C] != -2;          // wave-uniform
 #pragma unroll
       for (int a = 0; a < NPL; ++a) {
         k[u][a] = 0.f;
-        if (t < T && lane + 64 * a < D) {
-          int id = ids[t * C + rr[a]];
-          valid[u] = id != -2;
+        if (valid[u] && lane + 64 * a < D) {
+          int id = attn_ids[t * C + rr[a]];
           if (id >= 0) k[u][a] = embed[(int64_t)id * ld + ee[a]];
         }
       }
@@ -347,18 +414,19 @@ __global__ __launch_bounds__(256) void ip_attn_kernel(const float* __restrict__ 
     for (int u = 0; u < TB; ++u) {
       int t = t0 + u;
       if (t >= T) break;
-      // valid[] is lane-uniform except for lanes beyond D; take lane 0's view
-      bool m = __shfl((int)valid[u], 0, 64) != 0;
-      float part = 0.f;
+      float dot = 0.f;
+      if (valid[u]) {
+        float part = 0.f;
 #pragma unroll
-      for (int a = 0; a < NPL; ++a) part += (BWD ? gp[a] : qv[a]) * k[u][a];
-      float dot = m ? wave_sum64(part) : 0.f;
+        for (int a = 0; a < NPL; ++a) part += (BWD ? gp[a] : qv[a]) * k[u][a];
+        dot = wave_sum64(part);
+      }
       if (!BWD) {
         if (lane == 0) scores[b * T + t] = dot;
 #pragma unroll
         for (int a = 0; a < NPL; ++a) acc[a] += dot * k[u][a];
       } else {
-        float s = scores[b * T + t];
+        float s = valid[u] ? scores[b * T + t] : 0.f;
 #pragma unroll
         for (int a = 0; a < NPL; ++a) {
           acc[a] += dot * k[u][a];
@@ -368,17 +436,18 @@ __global__ __launch_bounds__(256) void ip_attn_kernel(const float* __restrict__ 
     }
   }
 #pragma unroll
-  for (int a = 0; a < NPL; ++a) {
-    int d = lane + 64 * a;
-    if (d < D) {
-      if (!BWD) pooled[b * ld_p + d] = acc[a];
-      else gq[b * D + d] = acc[a];
-    }
+  for (int a = 0; a < NPL; ++a)
+    if (lane + 64 * a < D) partial[wave * D + lane + 64 * a] = acc[a];
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float v = (partial[d] + partial[D + d]) + (partial[2 * D + d] + partial[3 * D + d]);
+    if (!BWD) pooled[b * ld_p + d] = v;
+    else gq[b * D + d] = v;
   }
 }
 
 #define IP_ATTN_LAUNCH(NPL, BWD)                                                                                   \
-  hipLaunchKernelGGL((ip_attn_kernel<NPL, BWD>), dim3((unsigned)ceil_div64(B, 4)), dim3(256), lds, as_stream(stream), \
+  hipLaunchKernelGGL((ip_attn_kernel<NPL, BWD>), dim3((unsigned)B), dim3(256), lds, as_stream(stream), \
                      embed, ld, V, E, C, series, B, T, q, ld_q, padding_index, scores, pooled, ld_p, gpooled, ld_gp,   \
                      gkeys, gq, oob_flag)
 
@@ -389,7 +458,7 @@ static int ip_attn_launch(bool bwd, const float* embed, int64_t ld, int64_t V, i
   const int D = C * E;
   if (V <= 0 || V > INT32_MAX || E <= 0 || C <= 0 || ld < E || B < 0 || T <= 0 || D > 256 || ld_q < D)
     return REC_E_ARG;
-  const size_t lds = (size_t)4 * T * C * 4;
+  const size_t lds = (size_t)T * C * 4 + (size_t)4 * D * 4;
   if (lds > 64 * 1024) return REC_E_ARG;
   if (B == 0) return REC_OK;
   if (!embed || !series || !q || !scores) return REC_E_ARG;

@@ -592,9 +592,10 @@ def batchnorm_fwd(x, gamma, beta, moving_mean, moving_var, training, eps=1e-3, m
     y = torch.empty_like(x)
     xhat = torch.empty_like(x) if save else None
     rstd = torch.empty(N, dtype=torch.float32, device=x.device) if save else None
+    ws = torch.empty(lib.rec_batchnorm_workspace_bytes(B, N) // 4, dtype=torch.float32, device=x.device)
     check(lib.rec_batchnorm_fwd_f32(_ptr(x), N, B, N, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
                                     1 if training else 0, _ptr(moving_mean), _ptr(moving_var), _ptr(y), _ptr(xhat),
-                                    _ptr(rstd), _stream()), "rec_batchnorm_fwd_f32")
+                                    _ptr(rstd), _ptr(ws), _stream()), "rec_batchnorm_fwd_f32")
     return y, xhat, rstd
 
 
@@ -604,8 +605,9 @@ def batchnorm_bwd(g, xhat, rstd, gamma, training):
     gx = torch.empty_like(g)
     ggamma = torch.empty(N, dtype=torch.float32, device=g.device)
     gbeta = torch.empty(N, dtype=torch.float32, device=g.device)
+    ws = torch.empty(lib.rec_batchnorm_workspace_bytes(B, N) // 4, dtype=torch.float32, device=g.device)
     check(lib.rec_batchnorm_bwd_f32(_ptr(g), _ptr(xhat), _ptr(rstd), B, N, _ptr(gamma), 1 if training else 0, _ptr(gx),
-                                    _ptr(ggamma), _ptr(gbeta), _stream()), "rec_batchnorm_bwd_f32")
+                                    _ptr(ggamma), _ptr(gbeta), _ptr(ws), _stream()), "rec_batchnorm_bwd_f32")
     return gx, ggamma, gbeta
 
 

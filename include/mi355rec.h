@@ -358,12 +358,13 @@ int rec_ffm_bwd_rows_f32(const float* v, int64_t ld_v, int64_t V, int E, const i
 /* ---- tf.keras.layers.BatchNormalization on [B,N] (3.DCN/CustomLayers.py:466,504; 2.FM/CustomLayers.py:69,78-79).
  * training != 0: batch mean / biased batch variance, moving statistics updated in place with `momentum`;
  * training == 0: moving statistics.  xhat [B,N] and rstd [N] are saved for the backward (may be NULL at inference).
- * gamma / beta may be NULL (scale / center off). */
+ * gamma / beta may be NULL (scale / center off).  workspace: rec_batchnorm_workspace_bytes(B, N) device bytes. */
+size_t rec_batchnorm_workspace_bytes(int64_t B, int N);
 int rec_batchnorm_fwd_f32(const float* x, int64_t ld_x, int64_t B, int N, const float* gamma, const float* beta,
                           float eps, float momentum, int training, float* moving_mean, float* moving_var, float* y,
-                          float* xhat, float* rstd, void* stream);
+                          float* xhat, float* rstd, void* workspace, void* stream);
 int rec_batchnorm_bwd_f32(const float* g, const float* xhat, const float* rstd, int64_t B, int N, const float* gamma,
-                          int training, float* gx, float* ggamma, float* gbeta, void* stream);
+                          int training, float* gx, float* ggamma, float* gbeta, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

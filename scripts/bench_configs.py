@@ -9,6 +9,9 @@ batches, one MI355X.  Prints one JSON line per config.  Usage:  python scripts/b
   D   DSSM two-tower, item V=100M x 64d on ONE GPU (25.6 GB table; the 8-way sharded form is sharded.py), B=8192
   E   DIN, T=100, V=50M, E=32, B=4096
   R   retrieval after the towers: 10M items x 8d (L2-normalised), 1024 user vectors, top-20
+  P   PNN inner product (f4), 26 fields, V=10M, E=16, B=8192      N   NFM (f4), 10 cat + 3 cont, V=10M, E=16, B=16384
+  FF  FFM (f4), 26 fields, V=10M rows of 26x16 floats (16.6 GB), B=8192
+  G   SIM GSU inner-product attention (f4), T=100, V=50M, E=32, B=4096
 """
 import json
 import os
@@ -131,6 +134,53 @@ def run(name):
         dt = timed(fwd_bwd(layer, batch, user + item + ser), 2, 10)
         return {"config": "E DIN T=100, 50M x 32d", "B": B, "V": V, "ms_per_step": dt * 1e3, "examples_per_s": B / dt,
                 "attention_flops_factorised_fwd": 2.0 * B * 96 * 96 * 36 + 2.0 * B * T * 96 * 36}
+    if name == "P":
+        names = ["C%d" % i for i in range(26)]
+        V, B = 10_000_000, 8192
+        layer = layers.PNNLayer(feature_names=names, feature_dims=1000, embedding_dims=16).cuda()
+        layer.embed.embeddings = torch.nn.Parameter(torch.empty((V, 16), device="cuda"))
+        big_table_(layer.embed.embeddings)
+        batch = data.to_device(data.SyntheticGenerator(names, V, seed=0).batch(B))
+        dt = timed(fwd_bwd(layer, batch, names), 5, 50)
+        return {"config": "P PNN inner product, 26 fields, 10M x 16d", "B": B, "V": V, "ms_per_step": dt * 1e3,
+                "examples_per_s": B / dt}
+    if name == "N":
+        cat = ["c%d" % i for i in range(10)]
+        cont = ["x0", "x1", "x2"]
+        V, B = 10_000_000, 16384
+        layer = layers.NeuralFactorizationMachineLayer(categorical_features=cat, continuous_features=cont,
+                                                       feature_dims=1000, embedding_dims=16).cuda()
+        layer.embed.embeddings = torch.nn.Parameter(torch.empty((V, 16), device="cuda"))
+        big_table_(layer.embed.embeddings)
+        batch = data.to_device(data.SyntheticGenerator(cat, V, continuous=cont, seed=0).batch(B))
+        dt = timed(fwd_bwd(layer, batch, cat + cont), 5, 50)
+        return {"config": "N NFM bi-interaction + BatchNormalization, 10 cat + 3 cont, 10M x 16d", "B": B, "V": V,
+                "ms_per_step": dt * 1e3, "examples_per_s": B / dt}
+    if name == "FF":
+        names = ["C%d" % i for i in range(26)]
+        V, B, E = 10_000_000, 8192, 16
+        layer = layers.FFMLayer(feature_names=names, feature_dims=1000, embedding_dims=E).cuda()
+        layer.fa_interaction_layer.v = torch.nn.Parameter(torch.empty((V, 26, E), device="cuda"))
+        layer.w = torch.nn.Parameter(torch.empty((V, 1), device="cuda"))
+        big_table_(layer.fa_interaction_layer.v)
+        big_table_(layer.w)
+        batch = data.to_device(data.SyntheticGenerator(names, V, seed=0).batch(B))
+        dt = timed(fwd_bwd(layer, batch, names), 3, 20)
+        return {"config": "FF FFM, 26 fields, 10M rows x (26 x 16d)", "B": B, "V": V, "ms_per_step": dt * 1e3,
+                "examples_per_s": B / dt, "row_bytes_gathered_fwd": B * 26 * 25 * E * 4}
+    if name == "G":
+        item = ["i_goods_id", "i_shop_id", "i_cate_id"]
+        ser = ["visited_goods_ids", "visited_shop_ids", "visited_cate_ids"]
+        V, B, E, T = 50_000_000, 4096, 32, 100
+        layer = layers.GSULayer(item_categorical_features=item, behavior_series_features=ser, feature_dims=1000,
+                                embedding_dims=E).cuda()
+        layer.embed.embeddings = torch.nn.Parameter(torch.empty((V, E), device="cuda"))
+        big_table_(layer.embed.embeddings)
+        layer.feature_dims = V
+        batch = data.to_device(data.SyntheticGenerator(item, V, series=ser, seq_len=T, seed=0).batch(B))
+        dt = timed(fwd_bwd(layer, batch, item + ser), 3, 20)
+        return {"config": "G SIM GSU inner-product attention T=100, 50M x 32d", "B": B, "V": V, "ms_per_step": dt * 1e3,
+                "examples_per_s": B / dt}
     if name == "R":
         from explicit_tf2_recommendation_amd import ops
         n, d, nq, k = 10_000_000, 8, 1024, 20
@@ -150,7 +200,7 @@ if __name__ == "__main__":
     GRAPHED = "--graphed" in sys.argv[1:]
     for n in (argv or ["A", "B", "C", "C26", "D", "E", "R"]):
         r = run(n)
-        if GRAPHED and n in ("B", "C", "C26", "D", "E"):
+        if GRAPHED and n in ("B", "C", "C26", "D", "E", "P", "N", "FF", "G"):
             r["config"] += " [GraphedTrainStep]"
         r["n_gpus"] = 1
         print(json.dumps(r), flush=True)

@@ -225,6 +225,36 @@ def test_gemm_split_k_deterministic(ops, split):
     assert np.abs(C1 - ref).max() <= 2e-6 * np.sqrt(K) * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 32, 741), (8192, 32, 741), (257, 1, 8), (1000, 8, 32), (4096, 64, 192),
+                                    (300, 33, 17), (511, 2, 80), (2048, 64, 1), (290, 20, 129)])
+def test_gemm_tall_skinny(ops, M, N, K):
+    """N <= 64, row-major operands, M >= 256: the no-LDS kernel whose 4 waves split K (every MLP forward layer)."""
+    r = H.rng(M + N + K)
+    A = r.normal(size=(M, K)).astype(np.float32)
+    B = r.normal(size=(K, N)).astype(np.float32)
+    bias = r.normal(size=(N,)).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    tol = 2e-6 * np.sqrt(K) * max(1.0, np.abs(ref).max())
+    C = ops.gemm(dev(A), dev(B)).cpu().numpy()
+    assert np.abs(C - ref).max() <= tol
+    assert np.array_equal(C, ops.gemm(dev(A), dev(B)).cpu().numpy())                 # deterministic
+    Cr = ops.gemm(dev(A), dev(B), epi=ops.EPI_BIAS_RELU, bias=dev(bias)).cpu().numpy()
+    assert np.abs(Cr - np.maximum(ref + bias, 0)).max() <= tol
+    # A as a column slice of a wider matrix (leading dimension != K), C into a column slice of a wider buffer
+    wide = torch.zeros((M, K + 5), device="cuda")
+    wide[:, 3:3 + K] = dev(A)
+    outw = torch.full((M, N + 7), -1.0, device="cuda")
+    ops.gemm(wide[:, 3:3 + K], dev(B), out=outw[:, 2:2 + N])
+    assert np.abs(outw[:, 2:2 + N].cpu().numpy() - ref).max() <= tol
+    assert torch.all(outw[:, :2] == -1) and torch.all(outw[:, 2 + N:] == -1)
+    e0 = r.normal(size=(M, N)).astype(np.float32)
+    e1 = r.normal(size=(M, N)).astype(np.float32)
+    aux = torch.empty((M, N), device="cuda")
+    Cc = ops.gemm(dev(A), dev(B), epi=ops.EPI_CROSS, bias=dev(bias), e0=dev(e0), e1=dev(e1), aux=aux).cpu().numpy()
+    assert np.abs(Cc - (e0 * (ref + bias) + e1)).max() <= 4 * tol
+    assert np.abs(aux.cpu().numpy() - (ref + bias)).max() <= tol
+
+
 def test_dense_helpers(ops):
     r = H.rng(12)
     post = r.normal(size=(100, 33)).astype(np.float32)
