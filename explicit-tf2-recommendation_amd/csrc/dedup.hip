@@ -222,57 +222,96 @@ __global__ __launch_bounds__(256) void segsum_chunk_kernel(const float* __restri
   }
 }
 
-// One lane group (LPR lanes x float4) per unique id; rows of the run are added in sorted (= position) order;
-// long runs add their chunk partials in chunk order.
+// One lane group (LPR lanes x float4) per unique id; rows of the run are added in sorted (= position) order.
+// A long run (DIN's / SIM's padding id: 600k rows = 2400 chunk partials) is finished by the WHOLE workgroup: its
+// 256/lpr lane groups each add a fixed strided subset of the chunk partials (4 loads in flight per lane), and the
+// groups meet in a fixed tree through LDS -- one lane group walking 2400 partials alone was a 250-us critical path.
 __global__ __launch_bounds__(256) void segsum_vec_kernel(const float4* __restrict__ vals, int lpr,
                                                          const int32_t* __restrict__ perm,
                                                          const int32_t* __restrict__ seg_start, int64_t n,
                                                          int32_t row_div, const float4* __restrict__ part,
                                                          float4* __restrict__ out) {
+  __shared__ int long_cnt;
+  __shared__ int long_u[256];
+  __shared__ float4 red[256];
+  if (threadIdx.x == 0) long_cnt = 0;
+  __syncthreads();
   int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= n * lpr) return;
-  int64_t u = t / lpr;
-  int c = (int)(t - u * lpr);
-  int s0 = seg_start[u], s1 = seg_start[u + 1];
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (s1 - s0 <= LONG) {
-    for (int s = s0; s < s1; ++s) {
-      int64_t src = perm[s] / row_div;
-      float4 v = vals[src * lpr + c];
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-  } else {
-    // chunk partials in chunk order.  A run of 600k rows (DIN's padding id) has 2400 of them: eight independent chains
-    // (chunk j of every eight -> chain j) keep eight loads in flight, the chains meet in a fixed tree
-    const int chb = s0 / CH, che = (s1 - 1) / CH;
-    {
-      int which = s0 <= chb * CH ? 0 : 1;
-      acc = part[((int64_t)chb * 2 + which) * lpr + c];
-    }
-    float4 a8[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) a8[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    int ch = chb + 1;                                        // every later chunk starts inside the run: slot 0
-    for (; ch + 8 <= che + 1; ch += 8) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float4 v = part[((int64_t)(ch + j) * 2) * lpr + c];
-        a8[j].x += v.x; a8[j].y += v.y; a8[j].z += v.z; a8[j].w += v.w;
+  if (t < n * lpr) {
+    int64_t u = t / lpr;
+    int c = (int)(t - u * lpr);
+    int s0 = seg_start[u], s1 = seg_start[u + 1];
+    if (s1 - s0 <= LONG) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s = s0; s < s1; ++s) {
+        int64_t src = perm[s] / row_div;
+        float4 v = vals[src * lpr + c];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
+      out[t] = acc;
+    } else if (c == 0 || threadIdx.x == 0) {
+      // the first lane of the run inside this workgroup enters it (a run whose lanes straddle two workgroups is
+      // finished by both, with identical results)
+      long_u[atomicAdd(&long_cnt, 1)] = (int)u;
     }
-    for (int j = 0; ch <= che; ++ch, ++j) {
-      float4 v = part[((int64_t)ch * 2) * lpr + c];
-      a8[j].x += v.x; a8[j].y += v.y; a8[j].z += v.z; a8[j].w += v.w;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      a8[j].x += a8[j + 4].x; a8[j].y += a8[j + 4].y; a8[j].z += a8[j + 4].z; a8[j].w += a8[j + 4].w;
-    }
-    a8[0].x += a8[2].x; a8[0].y += a8[2].y; a8[0].z += a8[2].z; a8[0].w += a8[2].w;
-    a8[1].x += a8[3].x; a8[1].y += a8[3].y; a8[1].z += a8[3].z; a8[1].w += a8[3].w;
-    acc.x += a8[0].x + a8[1].x; acc.y += a8[0].y + a8[1].y; acc.z += a8[0].z + a8[1].z; acc.w += a8[0].w + a8[1].w;
   }
-  out[t] = acc;
+  __syncthreads();
+  const int n_long = long_cnt;                              // workgroup-uniform
+  const int NG = 256 / lpr;                                 // lane groups that cooperate
+  const int g = threadIdx.x / lpr, c = threadIdx.x - g * lpr;
+  for (int q = 0; q < n_long; ++q) {
+    const int u = long_u[q];
+    const int s0 = seg_start[u], s1 = seg_start[u + 1];
+    const int chb = s0 / CH, che = (s1 - 1) / CH;
+    float4 a4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g < NG) {
+      // every chunk after the first starts inside the run: slot 0.  Group g takes chunks chb+1+g, +NG, ...; four
+      // independent chains per lane
+      int ch = chb + 1 + g;
+      for (; ch + 3 * NG <= che; ch += 4 * NG) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float4 v = part[((int64_t)(ch + j * NG) * 2) * lpr + c];
+          a4[j].x += v.x; a4[j].y += v.y; a4[j].z += v.z; a4[j].w += v.w;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {                         // at most three chunks are left for this group
+        int cj = ch + j * NG;
+        if (cj <= che) {
+          float4 v = part[((int64_t)cj * 2) * lpr + c];
+          a4[j].x += v.x; a4[j].y += v.y; a4[j].z += v.z; a4[j].w += v.w;
+        }
+      }
+      a4[0].x += a4[2].x; a4[0].y += a4[2].y; a4[0].z += a4[2].z; a4[0].w += a4[2].w;
+      a4[1].x += a4[3].x; a4[1].y += a4[3].y; a4[1].z += a4[3].z; a4[1].w += a4[3].w;
+      a4[0].x += a4[1].x; a4[0].y += a4[1].y; a4[0].z += a4[1].z; a4[0].w += a4[1].w;
+    }
+    __syncthreads();                                        // red[] of the previous run has been consumed
+    if (g < NG) red[threadIdx.x] = a4[0];
+    __syncthreads();
+    int live = NG;                                          // fixed tree over the groups: g += g + ceil(live/2)
+    while (live > 1) {
+      int half = (live + 1) >> 1;
+      if (g + half < live) {
+        float4 o = red[(g + half) * lpr + c];
+        float4 m = red[g * lpr + c];
+        m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+        red[g * lpr + c] = m;
+      }
+      live = half;
+      __syncthreads();
+    }
+    if (g == 0) {
+      int which = s0 <= chb * CH ? 0 : 1;
+      float4 first = part[((int64_t)chb * 2 + which) * lpr + c];
+      float4 m = red[c];
+      first.x += m.x; first.y += m.y; first.z += m.z; first.w += m.w;
+      out[(int64_t)u * lpr + c] = first;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void segsum_scalar_kernel(const float* __restrict__ vals, int E,
