@@ -302,7 +302,9 @@ extern "C" int rec_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
   }
   float* ws = split_k > 1 ? workspace : nullptr;
   hipStream_t st = as_stream(stream);
-  const bool big = M > 64 && N > 64;
+  // 128x128 tiles (register prefetch, 4x the MFMA work per barrier) only when they fill a good part of the chip;
+  // a mid-size product ([4096,352] x [352,200]: 64 big tiles) runs on 64x64 tiles instead (256 workgroups)
+  const bool big = M > 64 && N > 64 && ceil_div64(M, LM) * ceil_div64(N, LN) * split_k >= 160;
   if (!transA && !transB && N <= 64 && M >= 256 && split_k == 1) {
     dim3 grid((unsigned)ceil_div64(M, 32));
     if (N <= 32)

@@ -24,22 +24,48 @@ def _sparse_grad(plan, vals, E, shape, row_div=1):
     return SparseRowGrad(plan.uniq_ids, rows, plan.n_uniq, shape).to_sparse()
 
 
+class GradSink:
+    """One de-duplication per table per step for a layer with several lookups into the SAME table (DIN, SIM GSU:
+    profile / target-item rows through Gather, the behaviour series through the attention kernel).  The attention's
+    backward -- which autograd runs first, its query comes out of the Gather -- leaves its ids and its IndexedSlices
+    values here, written behind ``n_head`` free rows of one shared buffer; the Gather's backward then fills the head
+    with its own values and builds ONE plan over both id lists.  Without it torch concatenates the two sparse gradients
+    (a 157-MB copy at DIN config E) and each lookup sorts on its own."""
+
+    def __init__(self, n_head):
+        self.n_head = int(n_head)
+        self.ids = None
+        self.buf = None
+
+    def take(self):
+        ids, buf = self.ids, self.buf
+        self.ids = self.buf = None
+        return ids, buf
+
+
 class Gather(torch.autograd.Function):
     """Embedding(V,E)(X): K2.  Backward: sparse row gradient (K4)."""
 
     @staticmethod
-    def forward(ctx, table, X, oob):
+    def forward(ctx, table, X, oob, sink=None):
         out = ops.emb_gather(table, X, oob)
         ctx.save_for_backward(X)
         ctx.shape = tuple(table.shape)
+        ctx.sink = sink
         return out
 
     @staticmethod
     def backward(ctx, g):
         (X,) = ctx.saved_tensors
         V, E = ctx.shape
+        g = g.contiguous().reshape(-1, E)
+        ids, buf = ctx.sink.take() if ctx.sink is not None else (None, None)
+        if buf is not None:                                  # the series lookups of the same table ride along
+            buf[: g.shape[0]].copy_(g)
+            plan = ops.DedupPlan(torch.cat([X.reshape(-1), ids.reshape(-1)]), V)
+            return _sparse_grad(plan, buf, E, (V, E)), None, None, None
         plan = ops.DedupPlan(X, V)
-        return _sparse_grad(plan, g.contiguous().reshape(-1, E), E, (V, E)), None, None
+        return _sparse_grad(plan, g, E, (V, E)), None, None, None
 
 
 class UsedRowsL2(torch.autograd.Function):
@@ -288,7 +314,8 @@ class DinAttention(torch.autograd.Function):
     / bias b2.  Returns pooled [B,D] and the raw scores [B,T] (not differentiable)."""
 
     @staticmethod
-    def forward(ctx, embed, q, series, W1, b1, kind, alpha, mean, var, W2, b2, padding_index, mask_valid, oob):
+    def forward(ctx, embed, q, series, W1, b1, kind, alpha, mean, var, W2, b2, padding_index, mask_valid, oob,
+                sink=None):
         q = q.contiguous()
         B, D = q.shape
         H = W1.shape[1]
@@ -299,6 +326,7 @@ class DinAttention(torch.autograd.Function):
                                           padding_index, mask_valid, oob)
         ctx.save_for_backward(embed, q, series, Wcat, Wkd, Mext, alpha, mean, var, w2, b2, scores)
         ctx.cfg = (kind, padding_index, mask_valid, D, H)
+        ctx.sink = sink
         ctx.mark_non_differentiable(scores)
         return pooled, scores
 
@@ -308,8 +336,14 @@ class DinAttention(torch.autograd.Function):
         kind, padding_index, mask_valid, D, H = ctx.cfg
         V, E = embed.shape
         B = q.shape[0]
+        sink, buf, dst = ctx.sink, None, None
+        if sink is not None:                                 # values land behind the Gather's rows in one shared buffer
+            n_ser = series.numel()
+            buf = torch.empty((sink.n_head + n_ser, E), dtype=torch.float32, device=embed.device)
+            dst = buf[sink.n_head:].view(series.shape[0], series.shape[1], D)
         gkeys, gMext, gw2p, galphap, gb2p = ops.din_attn_bwd(embed, series, Mext, Wkd, kind, alpha, mean, var, w2, b2,
-                                                             padding_index, mask_valid, scores, gpooled.contiguous())
+                                                             padding_index, mask_valid, scores, gpooled.contiguous(),
+                                                             gkeys=dst)
         gq = ops.gemm(gMext, Wcat, transB=True)                                          # [B,D]
         gWcat = ops.gemm(q, gMext, transA=True, split_k=ops.split_k_for(B, D, D * H + H))  # [D, D*H+H]
         gbext = ops.colsum(gMext)
@@ -319,9 +353,13 @@ class DinAttention(torch.autograd.Function):
         gW2 = ops.colsum(gw2p).reshape(H, 1)
         galpha = ops.colsum(galphap) if alpha is not None else None
         gb2 = ops.colsum(gb2p)
-        plan = ops.DedupPlan(series, V)
-        gembed = _sparse_grad(plan, gkeys.reshape(-1, E), E, (V, E))
-        return gembed, gq, None, gW1, gb1, None, galpha, None, None, gW2, gb2, None, None, None
+        if sink is not None:
+            sink.ids, sink.buf = series, buf
+            gembed = None
+        else:
+            plan = ops.DedupPlan(series, V)
+            gembed = _sparse_grad(plan, gkeys.reshape(-1, E), E, (V, E))
+        return gembed, gq, None, gW1, gb1, None, galpha, None, None, gW2, gb2, None, None, None, None
 
 
 class EmbIpn(torch.autograd.Function):
@@ -377,11 +415,12 @@ class IpAttention(torch.autograd.Function):
     (7.SIM/CustomLayers.py:88-96,107-118).  Returns pooled [B,D] and the masked scores [B,T]."""
 
     @staticmethod
-    def forward(ctx, embed, q, series, padding_index, oob):
+    def forward(ctx, embed, q, series, padding_index, oob, sink=None):
         q = q.contiguous()
         scores, pooled = ops.ip_attn_fwd(embed, series, q, padding_index, oob)
         ctx.save_for_backward(embed, q, series, scores)
         ctx.padding_index = padding_index
+        ctx.sink = sink
         ctx.mark_non_differentiable(scores)
         return pooled, scores
 
@@ -389,9 +428,16 @@ class IpAttention(torch.autograd.Function):
     def backward(ctx, gpooled, _gscores):
         embed, q, series, scores = ctx.saved_tensors
         V, E = embed.shape
-        gkeys, gq = ops.ip_attn_bwd(embed, series, q, ctx.padding_index, scores, gpooled.contiguous())
+        sink, dst = ctx.sink, None
+        if sink is not None:
+            buf = torch.empty((sink.n_head + series.numel(), E), dtype=torch.float32, device=embed.device)
+            dst = buf[sink.n_head:].view(series.shape[0], series.shape[1], -1)
+        gkeys, gq = ops.ip_attn_bwd(embed, series, q, ctx.padding_index, scores, gpooled.contiguous(), gkeys=dst)
+        if sink is not None:
+            sink.ids, sink.buf = series, buf
+            return None, gq, None, None, None, None
         plan = ops.DedupPlan(series, V)
-        return _sparse_grad(plan, gkeys.reshape(-1, E), E, (V, E)), gq, None, None, None
+        return _sparse_grad(plan, gkeys.reshape(-1, E), E, (V, E)), gq, None, None, None, None
 
 
 class BatchNorm(torch.autograd.Function):

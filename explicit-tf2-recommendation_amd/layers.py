@@ -142,8 +142,15 @@ class Embedding(Layer):
         self.embeddings_regularizer = embeddings_regularizer
         self.embeddings = torch.nn.Parameter(_uniform((input_dim, output_dim), 0.05))
 
-    def forward(self, X, oob=None):
-        return Fn.Gather.apply(self.embeddings, X, oob)
+    def forward(self, X, oob=None, sink=None):
+        return Fn.Gather.apply(self.embeddings, X, oob, sink)
+
+    def grad_sink(self, X):
+        """A functional.GradSink for a second lookup of this table in the same step (None when no gradient is
+        recorded)."""
+        if torch.is_grad_enabled() and self.embeddings.requires_grad:
+            return Fn.GradSink(X.numel())
+        return None
 
 
 class MLPLayer(Layer):
@@ -608,12 +615,13 @@ class DinActivationLayer(Layer):
             return ops.DACT_PRELU, inner.alpha, None, None
         return inner.kind, None, None, None
 
-    def attend(self, embed, q, series, padding_index, mask_valid, oob=None):
+    def attend(self, embed, q, series, padding_index, mask_valid, oob=None, sink=None):
         """All T keys of every example at once: pooled [B,D], raw scores [B,T]."""
         dense = self.mlp_layer.layers[0]
         kind, alpha, mean, var = self.act_params()
         return Fn.DinAttention.apply(embed, q, series, dense.kernel, dense.bias, kind, alpha, mean, var,
-                                     self.output_layer.kernel, self.output_layer.bias, padding_index, mask_valid, oob)
+                                     self.output_layer.kernel, self.output_layer.bias, padding_index, mask_valid, oob,
+                                     sink)
 
     def forward(self, inputs):
         vec1, vec2 = inputs                       # q [B,D], k [B,D]
@@ -668,11 +676,14 @@ class DINLayer(Layer):
         prof_names = self.user_and_context_categorical_features + self.item_categorical_features
         X_cate = assemble_index(inputs, prof_names)
         flag = ops.new_flag(X_cate.device) if self.check_ids else None
-        profile = self.embed(X_cate, flag)
+        # one lookup serves both: the candidate item's rows are the tail of the profile rows (the reference looks the
+        # item ids up a second time, 5.DIN/CustomLayers.py:244-247 -- same values), and the series lookups of the
+        # attention share the profile lookup's de-duplication (functional.GradSink)
+        sink = self.embed.grad_sink(X_cate)
+        profile = self.embed(X_cate, flag, sink)
         profile_output = profile.reshape(profile.shape[0], -1)
-        X_item = assemble_index(inputs, self.item_categorical_features)
-        q = self.embed(X_item, flag)
-        q = q.reshape(q.shape[0], -1)
+        n_item = len(self.item_categorical_features)
+        q = profile[:, profile.shape[1] - n_item:, :].reshape(profile.shape[0], -1)
         series_cols = []
         for name in self.behavior_series_features:
             t = inputs[name]
@@ -685,7 +696,7 @@ class DINLayer(Layer):
         B, T = series_cols[0].shape
         series = ops.index_pack(series_cols).reshape(B, T, len(series_cols))      # tf.stack(axis=2)
         pooled, _ = self.din_activation_layer.attend(self.embed.embeddings, q, series, self.padding_index,
-                                                     1 if self.mask_mode == "valid" else 0, flag)
+                                                     1 if self.mask_mode == "valid" else 0, flag, sink)
         self._raise_if_oob(flag)
         X_combined = ConcatCols.apply(profile_output, pooled)
         return {"output": self.mlp(X_combined)}
@@ -815,7 +826,8 @@ class GSULayer(Layer):
     def forward(self, inputs):
         X_item = assemble_index(inputs, self.item_categorical_features)
         flag = ops.new_flag(X_item.device) if self.check_ids else None
-        q = self.embed(X_item, flag)
+        sink = self.embed.grad_sink(X_item)        # the series lookups share the item lookup's de-duplication
+        q = self.embed(X_item, flag, sink)
         q = q.reshape(q.shape[0], -1)
         series_cols = []
         for name in self.behavior_series_features:
@@ -828,7 +840,7 @@ class GSULayer(Layer):
             series_cols.append(t)
         B, T = series_cols[0].shape
         series = ops.index_pack(series_cols).reshape(B, T, len(series_cols))      # tf.stack(axis=2)
-        pooled, _ = Fn.IpAttention.apply(self.embed.embeddings, q, series, self.padding_index, flag)
+        pooled, _ = Fn.IpAttention.apply(self.embed.embeddings, q, series, self.padding_index, flag, sink)
         self._raise_if_oob(flag)
         X_combined = ConcatCols.apply(q, pooled)
         result = {"output": self.mlp(X_combined), "valid_mask": series_cols[0] != self.padding_index}

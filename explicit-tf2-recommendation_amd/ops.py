@@ -187,8 +187,11 @@ def l2_used_rows(table, plan, factor):
 # dense
 # ---------------------------------------------------------------------------------------------------
 
-def gemm(A, B, transA=False, transB=False, epi=EPI_NONE, bias=None, e0=None, e1=None, split_k=1, out=None, aux=None):
-    """C = epi(op(A) @ op(B)) on the fp32 matrix cores.  A, B are 2-D row-major (leading dim = stride(0))."""
+def gemm(A, B, transA=False, transB=False, epi=EPI_NONE, bias=None, e0=None, e1=None, split_k=None, out=None,
+         aux=None):
+    """C = epi(op(A) @ op(B)) on the fp32 matrix cores.  A, B are 2-D row-major (leading dim = stride(0)).
+    ``split_k=None``: chosen by split_k_for (a deep reduction over few output tiles is cut into slices that are added
+    in slice order -- e.g. DIN's gq = gMext . Wcat^T, [4096,3492] x [3492,96], ran on 32 workgroups)."""
     for t, nm in ((A, "A"), (B, "B")):
         if t.dtype != torch.float32 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
             raise ValueError("%s must be a 2-D fp32 CUDA tensor with unit inner stride" % nm)
@@ -198,6 +201,9 @@ def gemm(A, B, transA=False, transB=False, epi=EPI_NONE, bias=None, e0=None, e1=
         raise ValueError("gemm inner dimensions differ: %d vs %d" % (K, K2))
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    if split_k is None:
+        skinny = (not transA) and (not transB) and N <= 64 and M >= 256      # the no-LDS kernel splits K over its waves
+        split_k = 1 if skinny else split_k_for(K, M, N)
     ws = None
     if split_k > 1:
         ws = torch.empty((split_k, M, N), dtype=torch.float32, device=A.device)
@@ -443,12 +449,16 @@ def din_attn_fwd(embed, series, Mext, Wkd, act, alpha, mean, var, w2, b2, paddin
     return scores, pooled
 
 
-def din_attn_bwd(embed, series, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index, mask_valid, scores, gpooled):
+def din_attn_bwd(embed, series, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index, mask_valid, scores, gpooled,
+                 gkeys=None):
+    """``gkeys``: optional preallocated contiguous [B,T,D] destination (the tail of a shared value buffer)."""
     args, (B, T, D, H) = _attn_common(embed, series, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index,
                                       mask_valid)
     dev = embed.device
     f32 = dict(dtype=torch.float32, device=dev)
-    gkeys = torch.empty((B, T, D), **f32)
+    if gkeys is None:
+        gkeys = torch.empty((B, T, D), **f32)
+    _f32(gkeys, "gkeys")
     gMext = torch.empty((B, D * H + H), **f32)
     gw2p = torch.empty((B, H), **f32)
     galphap = torch.empty((B, H), **f32)
@@ -572,12 +582,14 @@ def ip_attn_fwd(embed, series, q, padding_index, oob=None):
     return scores, pooled
 
 
-def ip_attn_bwd(embed, series, q, padding_index, scores, gpooled):
+def ip_attn_bwd(embed, series, q, padding_index, scores, gpooled, gkeys=None):
     _table(embed, "embed"); _i64(series, "series"); _f32(q, "q"); _f32(scores, "scores"); _f32(gpooled, "gpooled")
     V, E = embed.shape
     B, T, C = series.shape
     D = C * E
-    gkeys = torch.empty((B, T, D), dtype=torch.float32, device=embed.device)
+    if gkeys is None:
+        gkeys = torch.empty((B, T, D), dtype=torch.float32, device=embed.device)
+    _f32(gkeys, "gkeys")
     gq = torch.empty((B, D), dtype=torch.float32, device=embed.device)
     check(lib.rec_ip_attn_bwd_f32(_ptr(embed), embed.stride(0), V, E, C, _ptr(series), B, T, _ptr(q), q.shape[1],
                                   int(padding_index), _ptr(scores), _ptr(gpooled), gpooled.shape[1], _ptr(gkeys),
