@@ -777,15 +777,29 @@ class ShardedDeepFMStep:
         self.table_shard = torch.zeros((self.rows_per_shard, 32), **f32)
         self.table_shard[: hi - lo].copy_(fused[lo:hi])
         self.n = B * F
-        self.loss = torch.empty(1, **f32)
         self.oob = torch.zeros(1, dtype=torch.int32, device=dev)
         D = F * 16
-        self.g = {
-            "MLP_layer1.kernel_0": torch.empty((D, 32), **f32), "MLP_layer1.bias_0": torch.empty(32, **f32),
-            "MLP_layer1.kernel_1": torch.empty((32, 8), **f32), "MLP_layer1.bias_1": torch.empty(8, **f32),
-            "MLP_layer2.kernel_0": torch.empty((8, 1), **f32), "MLP_layer2.bias_0": torch.empty(1, **f32),
-            "bias": torch.empty(1, **f32),
-        }
+        # the dense gradients and the loss are views of ONE flat buffer: C4 is a single in-place all-reduce, no
+        # concatenation before it and no copies after it (every view starts on a 16-byte boundary)
+        shapes = [("MLP_layer1.kernel_0", (D, 32)), ("MLP_layer1.bias_0", (32,)), ("MLP_layer1.kernel_1", (32, 8)),
+                  ("MLP_layer1.bias_1", (8,)), ("MLP_layer2.kernel_0", (8, 1)), ("MLP_layer2.bias_0", (1,)),
+                  ("bias", (1,)), ("loss", (1,))]
+        offs, total = [], 0
+        for _, shp in shapes:
+            offs.append(total)
+            k = 1
+            for d in shp:
+                k *= d
+            total += (k + 3) // 4 * 4
+        self.flat = torch.zeros(total, **f32)
+        views = {}
+        for (name, shp), off in zip(shapes, offs):
+            k = 1
+            for d in shp:
+                k *= d
+            views[name] = self.flat[off:off + k].view(shp)
+        self.loss = views.pop("loss")
+        self.g = views
         self.be = (backend or HipStepBackend)(self, field_dims, field_offsets)
         self._next = None               # (key, buffer, plan) announced by the previous call
         self.table_grad = None          # (local uniq ids, embed rows [.,16], w rows [.,1], n_uniq) after a step
@@ -842,15 +856,8 @@ class ShardedDeepFMStep:
             self.table_grad = None
         # C4: dense gradients and the loss, one flat all-reduce (mean over ranks = the global-batch gradient)
         if self.P > 1:
-            g = self.g
-            flat = torch.cat([t.reshape(-1) for t in g.values()] + [self.loss])
-            comm.all_reduce_sum(flat)
-            flat /= self.P
-            off = 0
-            for t in list(g.values()) + [self.loss]:
-                k = t.numel()
-                t.copy_(flat[off:off + k].reshape(t.shape))
-                off += k
+            comm.all_reduce_sum(self.flat)
+            self.flat /= self.P
         return self.loss
 
     def check_flags(self):
