@@ -10,6 +10,7 @@
 // example, the gather of the T key rows, the [T,D] x [D,H] product against Eff_b held in LDS, the activation, the
 // score, the (reference-quirk) mask and the weighted sum pooling -- keys are never written to HBM in the forward.
 #include "common.h"
+#include <stdlib.h>
 #include <math.h>
 
 namespace {
@@ -123,6 +124,7 @@ struct AttnArgs {
   int act; const float* alpha; const float* mean; const float* var;
   const float* w2; const float* b2;
   int64_t padding_index; int mask_valid;
+  int stop;      // diagnostics only (REC_DIN_STOP): leave the forward kernel after phase `stop`; 0 = run everything
 };
 
 struct AttnLds {
@@ -157,48 +159,148 @@ __device__ __forceinline__ void attn_load_eff(const AttnArgs& a, int64_t b, int 
   float* cvec = lds + L.cvec;
   float* KT = lds + L.kt;
   const int64_t NM = (int64_t)D * H + H;
-  for (int i = threadIdx.x; i < L.Dp * L.HS; i += 256) {
-    int r = i / L.HS, o = i - r * L.HS;
-    Eff[i] = (r < D && o < H) ? a.Wkd[r * H + o] + a.Mext[b * NM + (int64_t)r * H + o] : 0.f;
+  const float* mrow = a.Mext + b * NM;
+  const int DH = D * H;
+  if ((DH & 3) == 0 && (NM & 3) == 0 &&
+      ((reinterpret_cast<uintptr_t>(a.Mext) | reinterpret_cast<uintptr_t>(a.Wkd)) & 15) == 0) {
+    // the row [Eff part D*H | c part H] is streamed as float4 (4 per lane in flight) and scattered into the padded tile
+    for (int i = threadIdx.x; i < L.Dp * L.HS; i += 256) {           // padding entries first (disjoint from the rest)
+      int r = i / L.HS, o = i - r * L.HS;
+      if (r >= D || o >= H) Eff[i] = 0.f;
+    }
+    for (int o = H + threadIdx.x; o < L.Hp; o += 256) cvec[o] = 0.f;
+    const float4* m4 = reinterpret_cast<const float4*>(mrow);
+    const float4* w4 = reinterpret_cast<const float4*>(a.Wkd);
+    const int n4 = (int)(NM >> 2), dh4 = DH >> 2;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 256 * 4) {
+      float4 mv[4], wv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int i = i0 + u * 256;
+        mv[u] = wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n4) {
+          mv[u] = m4[i];
+          if (i < dh4) wv[u] = w4[i];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int i = i0 + u * 256;
+        if (i >= n4) continue;
+        float e[4] = {mv[u].x + wv[u].x, mv[u].y + wv[u].y, mv[u].z + wv[u].z, mv[u].w + wv[u].w};
+        int f = 4 * i;
+        if (i < dh4) {
+          int r = f / H, o = f - r * H;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            Eff[r * L.HS + o] = e[j];
+            if (++o == H) { o = 0; ++r; }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) cvec[f - DH + j] = e[j];
+        }
+      }
+    }
+  } else {
+    const int n_eff = L.Dp * L.HS;
+    for (int i0 = threadIdx.x; i0 < n_eff; i0 += 256 * 6) {
+      float wv[6], mv[6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        int i = i0 + u * 256;
+        wv[u] = mv[u] = 0.f;
+        if (i < n_eff) {
+          int r = i / L.HS, o = i - r * L.HS;
+          if (r < D && o < H) { wv[u] = a.Wkd[r * H + o]; mv[u] = mrow[(int64_t)r * H + o]; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        int i = i0 + u * 256;
+        if (i < n_eff) Eff[i] = wv[u] + mv[u];
+      }
+    }
+    for (int o = threadIdx.x; o < L.Hp; o += 256) cvec[o] = o < H ? mrow[(int64_t)DH + o] : 0.f;
   }
-  for (int o = threadIdx.x; o < L.Hp; o += 256) cvec[o] = o < H ? a.Mext[b * NM + (int64_t)D * H + o] : 0.f;
   const int padc = L.DS - D;                               // columns D .. DS-1 of every KT row stay zero
   for (int i = threadIdx.x; i < TC * padc; i += 256) KT[(i / padc) * L.DS + D + i % padc] = 0.f;
 }
 
-// key rows t0 .. t0+TC-1 -> KT (rows beyond T and rows of out-of-range ids: zeros), mask of every row -> maskb
+// key rows t0 .. t0+TC-1 -> KT (rows beyond T and rows of out-of-range ids: zeros), mask of every row -> maskb.
+// One lane per 16 bytes of a row, six independent loads per lane issued before the first is consumed: a lane that
+// walked a whole 128-byte row by itself (load, wait, store, eight times) made this phase eight dependent memory round
+// trips per chunk, and with 2-3 workgroups per CU that latency WAS the kernel (forward 160 us at config E).
 __device__ __forceinline__ void attn_gather(const AttnArgs& a, int64_t b, int t0, int D, const AttnLds& L, float* lds,
                                             bool* bad) {
   float* KT = lds + L.kt;
   float* maskb = lds + L.maskb;
   const int E = a.E, C = a.C;
-  for (int idx = threadIdx.x; idx < TC * C; idx += 256) {
-    int row = idx / C, r = idx - row * C;
+  const int64_t* ser = a.series + (int64_t)b * a.T * C;
+  for (int row = threadIdx.x; row < TC; row += 256) {
     int t = t0 + row;
-    float* dst = KT + row * L.DS + r * E;
-    const float* src = nullptr;
+    float m = 0.f;
     if (t < a.T) {
-      int64_t id = a.series[((int64_t)b * a.T + t) * C + r];
-      if ((uint64_t)id < (uint64_t)a.V) src = a.embed + id * a.ld;
-      else *bad = true;
-      if (r == 0) {
-        bool pad = id == a.padding_index;
-        maskb[row] = (a.mask_valid ? !pad : pad) ? 1.f : 0.f;   // reference quirk: mask = (id == padding)
-      }
-    } else if (r == 0) {
-      maskb[row] = 0.f;
+      bool pad = ser[(int64_t)t * C] == a.padding_index;
+      m = (a.mask_valid ? !pad : pad) ? 1.f : 0.f;           // reference quirk: mask = (id == padding)
     }
-    if (src) {
-      if ((E & 3) == 0 && (a.ld & 3) == 0) {
-        for (int e = 0; e < E; e += 4) {
-          float4 v = *reinterpret_cast<const float4*>(src + e);
-          dst[e] = v.x; dst[e + 1] = v.y; dst[e + 2] = v.z; dst[e + 3] = v.w;
+    maskb[row] = m;
+  }
+  constexpr int NB = 6;
+  if ((E & 3) == 0 && (a.ld & 3) == 0) {
+    const int E4 = E >> 2, total = TC * C * E4;
+    for (int i0 = threadIdx.x; i0 < total; i0 += 256 * NB) {
+      float4 v[NB];
+      int off[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        int i = i0 + u * 256;
+        off[u] = -1;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < total) {
+          int rr = i / E4, e4 = i - rr * E4;
+          int row = rr / C, r = rr - row * C;
+          int t = t0 + row;
+          off[u] = row * L.DS + r * E + 4 * e4;
+          if (t < a.T) {
+            int64_t id = ser[(int64_t)t * C + r];
+            if ((uint64_t)id < (uint64_t)a.V) v[u] = *reinterpret_cast<const float4*>(a.embed + id * a.ld + 4 * e4);
+            else *bad = true;
+          }
         }
-      } else {
-        for (int e = 0; e < E; ++e) dst[e] = src[e];
       }
-    } else {
-      for (int e = 0; e < E; ++e) dst[e] = 0.f;
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        if (off[u] < 0) continue;
+        float* dst = KT + off[u];
+        dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
+      }
+    }
+  } else {
+    const int total = TC * C * E;
+    for (int i0 = threadIdx.x; i0 < total; i0 += 256 * NB) {
+      float v[NB];
+      int off[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        int i = i0 + u * 256;
+        off[u] = -1;
+        v[u] = 0.f;
+        if (i < total) {
+          int rr = i / E, e = i - rr * E;
+          int row = rr / C, r = rr - row * C;
+          int t = t0 + row;
+          off[u] = row * L.DS + r * E + e;
+          if (t < a.T) {
+            int64_t id = ser[(int64_t)t * C + r];
+            if ((uint64_t)id < (uint64_t)a.V) v[u] = a.embed[id * a.ld + e];
+            else *bad = true;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u)
+        if (off[u] >= 0) KT[off[u]] = v[u];
     }
   }
 }
@@ -257,12 +359,17 @@ __global__ __launch_bounds__(256) void din_attn_fwd_kernel(AttnArgs a, int D, in
   const float b2 = a.b2[0];
   float pacc[4] = {0.f, 0.f, 0.f, 0.f};                    // pooled dims lane, lane+64, lane+128, lane+192
   bool bad = false;
+  if (a.stop == 1) return;
   for (int t0 = 0; t0 < a.T; t0 += TC) {
     __syncthreads();                                       // Eff ready / previous chunk consumed
     attn_gather(a, b, t0, D, L, lds, &bad);
     __syncthreads();
+    if (a.stop == 2) continue;
+    if (t0 + r0 >= a.T) continue;                          // wave-uniform: all 16 rows of this wave are beyond T (no
+                                                           // barrier below in this iteration, zero contribution)
     f32x4 acc[NT];
     attn_pre_gemm<NT>(KT, Eff, L, r0, l15, g, acc);
+    if (a.stop == 3) { if (acc[0][0] == 12345.f) pacc[0] += 1.f; continue; }
     float sr[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -285,6 +392,7 @@ __global__ __launch_bounds__(256) void din_attn_fwd_kernel(AttnArgs a, int D, in
         msb[row] = maskb[row] * sr[r];
       }
     }
+    if (a.stop == 4) continue;
     // masked weighted sum of this wave's 16 key rows (msb of these rows was written by this wave)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -359,6 +467,8 @@ __global__ __launch_bounds__(256) void din_attn_bwd_kernel(AttnArgs a, int D, in
     __syncthreads();
     attn_gather(a, b, t0, D, L, lds, &bad);
     __syncthreads();
+    const bool wave_live = t0 + r0 < a.T;                  // wave-uniform: some of this wave's 16 rows are real steps
+    if (wave_live) {
     // (1) pre-activations of this wave's rows
     f32x4 acc[NT];
     attn_pre_gemm<NT>(KT, Eff, L, r0, l15, g, acc);
@@ -366,6 +476,7 @@ __global__ __launch_bounds__(256) void din_attn_bwd_kernel(AttnArgs a, int D, in
     {
       float dot = 0.f;
       const float* kr = KT + (r0 + l15) * L.DS + g;
+#pragma unroll 8
       for (int j = 0; j < (L.Dp >> 2); ++j) dot += gpl[4 * j + g] * kr[4 * j];
       dot += __shfl_xor(dot, 16, 64);
       dot += __shfl_xor(dot, 32, 64);
@@ -396,10 +507,12 @@ __global__ __launch_bounds__(256) void din_attn_bwd_kernel(AttnArgs a, int D, in
       }
     }
     if (l15 == 0) gb2a += (gsr[0] + gsr[1]) + (gsr[2] + gsr[3]);
-    __syncthreads();                                       // GP of all 64 rows
-    // (4) gEff += K^T . gpre over the chunk's rows
+    }
+    __syncthreads();                                       // GP of the chunk's live rows
+    // (4) gEff += K^T . gpre over the chunk's real steps (groups of 4; rows beyond T inside a group are zero in KT)
     {
-      const int nk = TC >> 2;
+      const int live_rows = a.T - t0 < TC ? a.T - t0 : TC;
+      const int nk = (live_rows + 3) >> 2;
       for (int k = 0; k < nk; ++k) {
         float bv[NT];
 #pragma unroll
@@ -416,7 +529,7 @@ __global__ __launch_bounds__(256) void din_attn_bwd_kernel(AttnArgs a, int D, in
       }
     }
     // (5) gkeys of this wave's rows: mask*score*g_pooled + gpre . Eff^T
-    {
+    if (wave_live) {
       const int nkh = L.Hp >> 2;
       float msr[4];
 #pragma unroll
@@ -425,6 +538,7 @@ __global__ __launch_bounds__(256) void din_attn_bwd_kernel(AttnArgs a, int D, in
         f32x4 ak = {0.f, 0.f, 0.f, 0.f};
         const float* ap = GP + (r0 + l15) * L.HS + g;
         const float* bp = Eff + (16 * dt + l15) * L.HS + g;
+#pragma unroll 4
         for (int k = 0; k < nkh; ++k) ak = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * k], bp[4 * k], ak, 0, 0, 0);
         int d = 16 * dt + l15;
         if (d < D) {
@@ -666,7 +780,8 @@ extern "C" int rec_din_attn_fwd_f32(const float* embed, int64_t ld, int64_t V, i
   if ((act == DACT_DICE && (!alpha || !mean || !var)) || (act == DACT_PRELU && !alpha)) return REC_E_ARG;
   size_t lds = attn_lds_bytes(D, H, false);
   if (lds > 150 * 1024) return REC_E_UNSUPPORTED;
-  AttnArgs a{embed, ld, V, E, C, series, T, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index, mask_valid};
+  static const int din_stop = getenv("REC_DIN_STOP") ? atoi(getenv("REC_DIN_STOP")) : 0;
+  AttnArgs a{embed, ld, V, E, C, series, T, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index, mask_valid, din_stop};
 #define LAUNCH_FWD(NT)                                                                                            \
   do {                                                                                                            \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_fwd_kernel<NT>),                   \
@@ -701,7 +816,7 @@ extern "C" int rec_din_attn_bwd_f32(const float* embed, int64_t ld, int64_t V, i
     return REC_E_ARG;
   size_t lds = attn_lds_bytes(D, H, true);
   if (lds > 150 * 1024) return REC_E_UNSUPPORTED;
-  AttnArgs a{embed, ld, V, E, C, series, T, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index, mask_valid};
+  AttnArgs a{embed, ld, V, E, C, series, T, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index, mask_valid, 0};
 #define LAUNCH_BWD(NT)                                                                                            \
   do {                                                                                                            \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_bwd_kernel<NT>),                   \
