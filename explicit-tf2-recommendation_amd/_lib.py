@@ -40,6 +40,7 @@ SIGNATURES = {
     "rec_bce_fwd_bwd_f32": (i32, [p, p, i64, p, p, p, p]),
     "rec_adam_dense_f32": (i32, [p, p, p, p, i64, i64, f32, f32, f32, f32, p]),
     "rec_adam_sparse_keras_f32": (i32, [p, i64, p, p, i64, i32, p, p, p, i64, p, i64, f32, f32, f32, f32, p]),
+    "rec_adam_sparse_keras_pair_f32": (i32, [p, i64, p, p, p, p, i64, i32, p, p, p, p, i64, p, p, i64, f32, f32, f32, f32, p]),
     "rec_adam_rows_f32": (i32, [p, i64, p, p, i64, i32, p, p, p, i64, i64, f32, f32, f32, f32, p]),
     "rec_l2_rows_workspace_bytes": (sz, [i64, i32]),
     "rec_l2_rows_f32": (i32, [p, i64, i64, i32, p, p, i64, f32, p, p, p, p]),

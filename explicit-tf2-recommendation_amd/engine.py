@@ -36,6 +36,13 @@ class _Program:
                 check(st, name)
 
 
+def _tables_share_rows(embed, w):
+    """embed [V,E] and w [V,1] are the two strided views of one fused [V,ld] array (layers._FMTables.fuse_tables)."""
+    E = embed.shape[1]
+    return (embed.is_cuda and E % 4 == 0 and embed.stride(0) == w.stride(0) and embed.stride(0) % 4 == 0
+            and embed.stride(0) >= E + 1 and w.data_ptr() == embed.data_ptr() + 4 * E and embed.data_ptr() % 16 == 0)
+
+
 class DeepFMTrainStep:
     """fwd + bwd (+ optimizer) of DeepFMRankingLayer (2.FM/CustomLayers.py:279-308) under the reference's loss.
 
@@ -173,6 +180,13 @@ class DeepFMTrainStep:
             m, v = self.state[name]
             P.add("rec_adam_dense_f32", _p(params[name]), _p(m), _p(v), _p(grad), grad.numel(), t, lr, b1, b2, eps)
         n = self.B * self.F
+        pe, pw = params["embed.embeddings"], params["w.embeddings"]
+        if self.optimizer == "keras_adam" and _tables_share_rows(pe, pw):
+            (me, ve), (mw, vw) = self.state["embed.embeddings"], self.state["w.embeddings"]
+            P.add("rec_adam_sparse_keras_pair_f32", _p(pe), pe.stride(0), _p(me), _p(ve), _p(mw), _p(vw), self.V, self.E,
+                  _p(self.uniq_ids), _p(self.g_embed_rows), _p(self.g_w_rows), _p(self.n_uniq), n, _p(self.side_e),
+                  _p(self.side_w), t, lr, b1, b2, eps)
+            return P
         for name, rows, side, E in (("embed.embeddings", self.g_embed_rows, self.side_e, self.E),
                                     ("w.embeddings", self.g_w_rows, self.side_w, 1)):
             m, v = self.state[name]
@@ -394,6 +408,15 @@ class DeepFMFusedStep:
             check(lib.rec_adam_dense_f32(_p(params[name]), _p(m), _p(v), _p(grad), grad.numel(), t, lr, b1, b2, eps, st),
                   "rec_adam_dense_f32")
         n = self.B * self.F
+        pe, pw = params["embed.embeddings"], params["w.embeddings"]
+        if self.optimizer == "keras_adam" and _tables_share_rows(pe, pw):
+            # one sweep over the fused [embed | w | pad] rows instead of one per table
+            (me, ve), (mw, vw) = self.state["embed.embeddings"], self.state["w.embeddings"]
+            check(lib.rec_adam_sparse_keras_pair_f32(_p(pe), pe.stride(0), _p(me), _p(ve), _p(mw), _p(vw), self.V, 16,
+                                                     _p(self.uniq_ids), _p(self.g_embed_rows), _p(self.g_w_rows),
+                                                     _p(self.n_uniq), n, _p(self.side_e), _p(self.side_w), t, lr, b1,
+                                                     b2, eps, st), "rec_adam_sparse_keras_pair_f32")
+            return
         for name, rows, side, E in (("embed.embeddings", self.g_embed_rows, self.side_e, 16),
                                     ("w.embeddings", self.g_w_rows, self.side_w, 1)):
             m, v = self.state[name]

@@ -171,6 +171,15 @@ int rec_adam_dense_f32(float* var, float* m, float* v, const float* g, int64_t n
 int rec_adam_sparse_keras_f32(float* var, int64_t ld, float* m, float* v, int64_t V, int E,
                               const int64_t* uniq_ids, const float* g_rows, const int64_t* n_uniq, int64_t cap,
                               float* side, int64_t t, float lr, float b1, float b2, float eps, void* stream);
+/* The same Keras sparse apply for BOTH tables of an FM-family layer that share the fused rows [embed(E) | w | pad]
+ * (fused = row 0 of the [V,ld] array; w = fused + E): one sweep over the lines instead of two -- swept on its own, w
+ * costs a full 128-byte line read + write per row.  Elementwise identical to two rec_adam_sparse_keras_f32 calls.
+ * side_e [cap,3,E], side_w [cap,3,1]. */
+int rec_adam_sparse_keras_pair_f32(float* fused, int64_t ld, float* m_e, float* v_e, float* m_w, float* v_w, int64_t V,
+                                   int E, const int64_t* uniq_ids, const float* g_e_rows, const float* g_w_rows,
+                                   const int64_t* n_uniq, int64_t cap, float* side_e, float* side_w, int64_t t,
+                                   float lr, float b1, float b2, float eps, void* stream);
+
 /* 'lazy' variant (NOT reference semantics): only the touched rows decay and move. */
 int rec_adam_rows_f32(float* var, int64_t ld, float* m, float* v, int64_t V, int E, const int64_t* uniq_ids,
                       const float* g_rows, const int64_t* n_uniq, int64_t cap, int64_t t, float lr,

@@ -365,6 +365,42 @@ def test_adam_dense_and_sparse(ops):
     assert np.abs(dvar.cpu().numpy() - a[0]).max() <= 2e-5
 
 
+def test_adam_sparse_keras_pair_equals_two_sweeps(ops):
+    """One sweep over the fused [embed | w | pad] rows == the two per-table sweeps, bit for bit (var, m, v)."""
+    from explicit_tf2_recommendation_amd._lib import lib, check
+    import ctypes as C
+    r = H.rng(21)
+    V, E, ld = 5000, 16, 32
+
+    def state():
+        fused = torch.zeros((V, ld), device="cuda")
+        fused[:, :E + 1] = dev(r0[:, :E + 1])
+        return [fused] + [dev(x.copy()) for x in (me0, ve0, mw0, vw0)]
+
+    r0 = r.normal(size=(V, ld)).astype(np.float32)
+    me0, ve0 = r.normal(size=(V, E)).astype(np.float32) * 0.1, r.uniform(0, 0.1, size=(V, E)).astype(np.float32)
+    mw0, vw0 = r.normal(size=(V, 1)).astype(np.float32) * 0.1, r.uniform(0, 0.1, size=(V, 1)).astype(np.float32)
+    ids = r.integers(0, 700, size=900)
+    plan = ops.DedupPlan(dev(ids), V)
+    ge = plan.segment_sum(dev(r.normal(size=(900, E)).astype(np.float32)), E)
+    gw = plan.segment_sum(dev(r.normal(size=(900, 1)).astype(np.float32)), 1)
+    a = state()
+    ops.adam_sparse_keras(a[0][:, :E], a[1], a[2], plan.uniq_ids, ge, plan.n_uniq, 3, 0.01)
+    ops.adam_sparse_keras(a[0][:, E:E + 1], a[3], a[4], plan.uniq_ids, gw, plan.n_uniq, 3, 0.01)
+    b = state()
+    cap = ge.shape[0]
+    side_e = torch.empty((cap, 3, E), device="cuda")
+    side_w = torch.empty((cap, 3, 1), device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    check(lib.rec_adam_sparse_keras_pair_f32(p(b[0]), ld, p(b[1]), p(b[2]), p(b[3]), p(b[4]), V, E, p(plan.uniq_ids),
+                                             p(ge), p(gw), p(plan.n_uniq), cap, p(side_e), p(side_w), 3, 0.01, 0.9,
+                                             0.999, 1e-7, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+          "rec_adam_sparse_keras_pair_f32")
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.all(b[0][:, E + 1:] == 0)                            # the padding floats of a row are never written
+
+
 # ---------------------------------------------------------------------------------------------
 # sharding (bit exact)
 # ---------------------------------------------------------------------------------------------
