@@ -123,7 +123,9 @@ def main():
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world,
+        import datetime
+        # a collective that never completes surfaces as an error after 5 minutes instead of the 10-minute default
+        dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=5),
                                 device_id=torch.device("cuda", local_rank))
     from explicit_tf2_recommendation_amd import layers, engine, data, ops
 

@@ -347,7 +347,8 @@ class DinAttention(torch.autograd.Function):
         gq = ops.gemm(gMext, Wcat, transB=True)                                          # [B,D]
         gWcat = ops.gemm(q, gMext, transA=True, split_k=ops.split_k_for(B, D, D * H + H))  # [D, D*H+H]
         gbext = ops.colsum(gMext)
-        gWkd = ops.colsum(gMext[:, :D * H]).reshape(D, H)     # Eff_b = Wkd + M_b  =>  dWkd = sum_b dEff_b
+        gWkd = gbext[:D * H].reshape(D, H)                    # Eff_b = Wkd + M_b  =>  dWkd = sum_b dEff_b: the leading
+                                                              # D*H column sums of gMext, already in gbext
         gW1 = ops.din_prepare_bwd(gWcat, gWkd, D, H)
         gb1 = gbext[D * H:].clone()
         gW2 = ops.colsum(gw2p).reshape(H, 1)

@@ -166,7 +166,9 @@ def make16(B, F, V, seed, dist):
 @pytest.mark.parametrize("B,F,V,dist", [(256, 5, 5547, "zipf"), (8192, 26, 1000000, "uniform"), (1000, 3, 300, "zipf"),
                                          (2048, 26, 200000, "zipf"), (33, 7, 4000, "uniform"), (64, 1, 500, "zipf"),
                                          (96, 2, 900, "uniform"), (160, 28, 60000, "zipf"), (70, 27, 60000, "uniform"),
-                                         (16384, 26, 2000000, "uniform")])
+                                         (16384, 26, 2000000, "uniform"),
+                                         (8192, 26, 10000000, "uniform"),      # BASELINE.json metric config, full size
+                                         (8192, 26, 10000000, "zipf")])
 def test_fused_step_matches_oracle(use_graph, B, F, V, dist):
     from explicit_tf2_recommendation_amd import engine, data
     layer, names, gen = make16(B, F, V, 11, dist)
