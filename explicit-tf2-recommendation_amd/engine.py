@@ -947,8 +947,18 @@ class GraphedTrainStep:
         return loss.detach()
 
     def __call__(self, batch):
+        # one multi-tensor copy per dtype instead of one tiny copy per feature column (26 + label for DeepFM)
+        groups = {}
         for k, v in self.static.items():
-            v.copy_(batch[k], non_blocking=True)
+            src = batch[k]
+            if src.dtype == v.dtype and src.device == v.device and src.shape == v.shape:
+                groups.setdefault(v.dtype, ([], []))
+                groups[v.dtype][0].append(v)
+                groups[v.dtype][1].append(src)
+            else:
+                v.copy_(src, non_blocking=True)
+        for dsts, srcs in groups.values():
+            torch._foreach_copy_(dsts, srcs)
         self.graph.replay()
         for p, g in zip(self.params, self.grads):
             p.grad = g
