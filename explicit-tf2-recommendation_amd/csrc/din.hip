@@ -124,7 +124,8 @@ struct AttnArgs {
   int act; const float* alpha; const float* mean; const float* var;
   const float* w2; const float* b2;
   int64_t padding_index; int mask_valid;
-  int stop;      // diagnostics only (REC_DIN_STOP): leave the forward kernel after phase `stop`; 0 = run everything
+  int stop;      // diagnostics only (REC_DIN_STOP, scripts/exp/din_{fwd,bwd}_phases.sh): forward 1-4 = leave after that
+                 // phase, backward 12-14 = skip the later steps; 0 = run everything
 };
 
 struct AttnLds {
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(256) void din_attn_bwd_kernel(AttnArgs a, int D, in
     __syncthreads();
     attn_gather(a, b, t0, D, L, lds, &bad);
     __syncthreads();
-    const bool wave_live = t0 + r0 < a.T;                  // wave-uniform: some of this wave's 16 rows are real steps
+    const bool wave_live = t0 + r0 < a.T && a.stop != 12;  // wave-uniform: some of this wave's 16 rows are real steps
     if (wave_live) {
     // (1) pre-activations of this wave's rows
     f32x4 acc[NT];
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(256) void din_attn_bwd_kernel(AttnArgs a, int D, in
     }
     __syncthreads();                                       // GP of the chunk's live rows
     // (4) gEff += K^T . gpre over the chunk's real steps (groups of 4; rows beyond T inside a group are zero in KT)
-    {
+    if (a.stop != 12 && a.stop != 13) {
       const int live_rows = a.T - t0 < TC ? a.T - t0 : TC;
       const int nk = (live_rows + 3) >> 2;
       for (int k = 0; k < nk; ++k) {
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(256) void din_attn_bwd_kernel(AttnArgs a, int D, in
       }
     }
     // (5) gkeys of this wave's rows: mask*score*g_pooled + gpre . Eff^T
-    if (wave_live) {
+    if (wave_live && a.stop != 13 && a.stop != 14) {
       const int nkh = L.Hp >> 2;
       float msr[4];
 #pragma unroll
@@ -816,7 +817,8 @@ extern "C" int rec_din_attn_bwd_f32(const float* embed, int64_t ld, int64_t V, i
     return REC_E_ARG;
   size_t lds = attn_lds_bytes(D, H, true);
   if (lds > 150 * 1024) return REC_E_UNSUPPORTED;
-  AttnArgs a{embed, ld, V, E, C, series, T, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index, mask_valid, 0};
+  static const int din_stop = getenv("REC_DIN_STOP") ? atoi(getenv("REC_DIN_STOP")) : 0;
+  AttnArgs a{embed, ld, V, E, C, series, T, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index, mask_valid, din_stop};
 #define LAUNCH_BWD(NT)                                                                                            \
   do {                                                                                                            \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_bwd_kernel<NT>),                   \
