@@ -14,6 +14,7 @@ SHAPES = [  # M, N, K, transA, transB
     (4096, 200, 352, False, False), (4096, 352, 200, False, True), (4096, 80, 200, False, False),
     (4096, 200, 80, False, True), (4096, 200, 192, False, False), (8192, 741, 32, False, True),
     (16384, 323, 323, False, True), (8192, 64, 192, False, False),
+    (16384, 835, 835, False, True), (16384, 835, 835, False, False), (835, 835, 16384, True, False),
 ]
 
 
