@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(int64_t M, int64_t
 constexpr int LM = 128, LN = 128, LK = 16, LPAD = 4;
 
 template <int TA, int TB>
-__global__ __launch_bounds__(256) void gemm_f32_big_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A,
+__global__ __launch_bounds__(256, 3) void gemm_f32_big_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A,
                                                            int64_t lda, const float* __restrict__ B, int64_t ldb,
                                                            float* __restrict__ C, int64_t ldc, int epi,
                                                            const float* __restrict__ bias, const float* __restrict__ e0,
