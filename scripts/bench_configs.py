@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Secondary measurements for the other BASELINE.json configs (parity-test cases, NOT the bench.py headline):
 forward + backward through the Layer mirror (autograd over the HIP kernels) on synthetic DataGenerator-contract
-batches, one MI355X.  Prints one JSON line per config.  Usage:  python scripts/bench_configs.py [A B C C26 D E]
+batches, one MI355X.  Prints one JSON line per config.  Usage:  python scripts/bench_configs.py [--graphed] [A B C C26 D E R P N FF G]
 
   A   FM, 5 fields, V=5547, E=16, B=256                       (BASELINE configs[0], via ModelManager)
   B   DeepFM, 26 fields, V=1M, E=16, B=8192                   (configs[1]; the 10M variant is bench.py)
@@ -198,7 +198,7 @@ def run(name):
 if __name__ == "__main__":
     argv = [a for a in sys.argv[1:] if a != "--graphed"]
     GRAPHED = "--graphed" in sys.argv[1:]
-    for n in (argv or ["A", "B", "C", "C26", "D", "E", "R"]):
+    for n in (argv or ["A", "B", "C", "C26", "D", "E", "R", "P", "N", "FF", "G"]):
         r = run(n)
         if GRAPHED and n in ("B", "C", "C26", "D", "E", "P", "N", "FF", "G"):
             r["config"] += " [GraphedTrainStep]"
