@@ -3,15 +3,18 @@
 // tf.unique of 5.DIN/ModelManager.py:185-186.  Deterministic: a stable radix sort puts the rows of one id
 // in ascending position order and every run is summed in that order -- no float atomics.
 //
-// The key/position radix sort is rocPRIM's device primitive (header-only, compiled here for gfx950); the
-// run detection, compaction and the segment sums are hand-written.
+// Everything here is hand-written: the (id, position) sort is an LSD radix sort built for this job (below), the
+// run detection, compaction and the segment sums follow it.  Each sort pass is three plain kernels (per-tile digit
+// histogram, per-digit scan over the tiles, stable scatter) -- no memsets, no host-side state, no cross-workgroup
+// hand-off inside a launch -- so a captured hipGraph of a plan replays like any other kernel chain, at every n.
+// (Round 1 used rocPRIM here; its Onesweep path, taken above 2^20 keys, keeps a 4-byte block-id word and the
+// look-back states alive through hipMemsetAsync nodes and faulted on graph replay.  Nothing of it is left.)
 //
 // Hot ids (a Zipf head, or DIN's padding id that fills half of every behaviour series) give runs of 10^5 rows;
 // a run longer than LONG rows is therefore cut into chunks of CH sorted positions that separate workgroups sum
 // (fixed slot order + fixed LDS tree), and the owner of the run adds the chunk partials in chunk order.
 #include "common.h"
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 namespace {
 
@@ -19,54 +22,228 @@ constexpr int TILE = 1024;  // sorted keys per workgroup in the run-detection ke
 constexpr int CH = 256;     // chunk of sorted positions in the long-run path
 constexpr int LONG = 256;   // runs longer than this take the chunked path (LONG >= CH: <= 2 long runs per chunk)
 
+// ---- LSD radix sort of (uint32 key, int32 position) pairs --------------------------------------------------------
+// Tile = 2048 keys per workgroup (4 waves x 8 rounds x 64 lanes; element = tile0 + wave*512 + round*64 + lane, so the
+// order (wave, round, lane) IS the input order and ranking in that order keeps the sort stable).  Digits are <= 8 bits;
+// `bits` significant key bits are split evenly over ceil(bits/8) passes.  Pass 0 reads the int64 ids themselves and
+// makes up the positions, so no key-preparation pass exists.
+constexpr int RS_TILE = 2048, RS_ROUNDS = 8, RS_BINS = 256;
+
 struct Layout {
-  size_t keys_in, keys_out, pos_in, tile_heads, sort_tmp, sort_tmp_bytes, total;
+  size_t keys_tmp, keys_out, pos_tmp, hist, tot, tile_heads, total;
 };
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
-// rocPRIM's radix sort switches from merge sort to its Onesweep algorithm above 2^20 items, and a captured hipGraph
-// that contains Onesweep faults when it is REPLAYED (memory aperture violation, seen with n = 1.27M: the DIN table
-// gradient at B = 4096, T = 100).  While the stream is being captured the merge-sort path is therefore kept for every size.
-// Block sorts of 4096 keys (512 threads x 8) up to 2^19 keys and of 8192 keys above, instead of the tuned default: two
-// or three merge passes (four or six launches) fewer (measured: DeepFM generic step 0.326 -> 0.308 ms at 213k keys with
-// 4096, DIN config E 1.588 -> 1.548 ms at 1.27M keys with 8192).
-using MergeSortOnly = rocprim::radix_sort_config<rocprim::default_config, rocprim::merge_sort_config<512, 512, 8>,
-                                                 rocprim::default_config, (size_t(1) << 40)>;
-using MergeSortOnlyLarge = rocprim::radix_sort_config<rocprim::default_config, rocprim::merge_sort_config<512, 512, 16>,
-                                                      rocprim::default_config, (size_t(1) << 40)>;
-constexpr int64_t MERGE_LARGE_N = int64_t(1) << 19;
-
 Layout make_layout(int64_t n) {
   Layout L;
   size_t off = 0;
-  L.keys_in = off; off = align256(off + sizeof(uint32_t) * n);
+  const size_t nb = (size_t)ceil_div64(n, RS_TILE);
+  L.keys_tmp = off; off = align256(off + sizeof(uint32_t) * n);
   L.keys_out = off; off = align256(off + sizeof(uint32_t) * n);
-  L.pos_in = off; off = align256(off + sizeof(int32_t) * n);
+  L.pos_tmp = off; off = align256(off + sizeof(int32_t) * n);
+  L.hist = off; off = align256(off + sizeof(uint32_t) * RS_BINS * nb);
+  L.tot = off; off = align256(off + sizeof(uint32_t) * RS_BINS);
   L.tile_heads = off; off = align256(off + sizeof(int32_t) * (size_t)(ceil_div64(n, TILE) + 1));
-  size_t tmp = 0, tmp2 = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr,
-                            (int32_t*)nullptr, (size_t)n, 0, 32, (hipStream_t)0);
-  (void)rocprim::radix_sort_pairs<MergeSortOnly>(nullptr, tmp2, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                                 (int32_t*)nullptr, (int32_t*)nullptr, (size_t)n, 0, 32, (hipStream_t)0);
-  if (tmp2 > tmp) tmp = tmp2;
-  (void)rocprim::radix_sort_pairs<MergeSortOnlyLarge>(nullptr, tmp2, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                                      (int32_t*)nullptr, (int32_t*)nullptr, (size_t)n, 0, 32,
-                                                      (hipStream_t)0);
-  if (tmp2 > tmp) tmp = tmp2;
-  L.sort_tmp = off;
-  L.sort_tmp_bytes = tmp;
-  off = align256(off + tmp);
   L.total = off;
   return L;
 }
 
-__global__ __launch_bounds__(256) void prep_keys_kernel(const int64_t* __restrict__ ids, int64_t n,
-                                                        uint32_t* __restrict__ keys, int32_t* __restrict__ pos) {
-  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= n) return;
-  keys[t] = (uint32_t)ids[t];
-  pos[t] = (int32_t)t;
+template <bool FIRST>
+__device__ __forceinline__ uint32_t rs_key(const int64_t* __restrict__ ids, const uint32_t* __restrict__ keys, int64_t i) {
+  if (FIRST) return (uint32_t)ids[i];
+  return keys[i];
+}
+
+// per-tile digit counts -> hist[digit * n_tiles + tile]
+template <bool FIRST>
+__global__ __launch_bounds__(256) void rs_hist_kernel(const int64_t* __restrict__ ids, const uint32_t* __restrict__ keys,
+                                                      int64_t n, int shift, uint32_t dmask, int n_tiles,
+                                                      uint32_t* __restrict__ hist) {
+  __shared__ unsigned int cnt[RS_BINS];
+  const int tid = threadIdx.x;
+  cnt[tid] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    int64_t i = base + r * 256 + tid;
+    if (i < n) atomicAdd(&cnt[(rs_key<FIRST>(ids, keys, i) >> shift) & dmask], 1u);   // integer LDS atomics: exact
+  }
+  __syncthreads();
+  hist[(int64_t)tid * n_tiles + blockIdx.x] = cnt[tid];
+}
+
+// one workgroup per digit: exclusive scan of that digit's counts over the tiles (in place) + the digit total
+__global__ __launch_bounds__(256) void rs_scan_kernel(uint32_t* __restrict__ hist, int n_tiles,
+                                                      uint32_t* __restrict__ tot) {
+  __shared__ unsigned int wave_tot[4];
+  __shared__ unsigned int carry_sh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t* row = hist + (int64_t)blockIdx.x * n_tiles;
+  unsigned int carry = 0;
+  for (int c0 = 0; c0 < n_tiles; c0 += 256) {
+    int i = c0 + tid;
+    unsigned int v = i < n_tiles ? row[i] : 0u;
+    unsigned int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      unsigned int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned int woff = 0;
+    for (int q = 0; q < wave; ++q) woff += wave_tot[q];
+    if (i < n_tiles) row[i] = carry + woff + incl - v;
+    if (tid == 255) carry_sh = carry + woff + incl;
+    __syncthreads();
+    carry = carry_sh;
+  }
+  if (tid == 0) tot[blockIdx.x] = carry;
+}
+
+// exclusive scan of 256 values held one per thread (result to every thread's own slot)
+__device__ __forceinline__ unsigned int rs_excl_scan_256(unsigned int v, unsigned int* wave_tot /*[4]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    unsigned int u = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += u;
+  }
+  __syncthreads();
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  unsigned int woff = 0;
+  for (int q = 0; q < wave; ++q) woff += wave_tot[q];
+  return woff + incl - v;
+}
+
+// stable scatter of one tile: rank every key among the tile's keys of the same digit (wave-level match by ballots,
+// per-wave digit counters in LDS), lay the tile out digit-sorted in LDS, then copy each digit's run to its global
+// slot: tile-exclusive count of the digit (rs_scan_kernel) + the digit's base (scan of the totals, redone here).
+template <bool FIRST>
+__global__ __launch_bounds__(256) void rs_scatter_kernel(const int64_t* __restrict__ ids,
+                                                         const uint32_t* __restrict__ keys_in,
+                                                         const int32_t* __restrict__ pos_in, int64_t n, int shift,
+                                                         int dbits, int n_tiles, const uint32_t* __restrict__ hist,
+                                                         const uint32_t* __restrict__ tot,
+                                                         uint32_t* __restrict__ keys_out, int32_t* __restrict__ pos_out) {
+  __shared__ unsigned int cnt[4][RS_BINS];       // per-wave digit counters, then the wave's base inside the tile
+  __shared__ unsigned int gpos[RS_BINS];         // global slot of the digit's run minus its start inside the tile
+  __shared__ unsigned int wave_tot[4];
+  __shared__ uint32_t st_key[RS_TILE];
+  __shared__ int32_t st_pos[RS_TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t dmask = (1u << dbits) - 1u;
+  const int64_t tile0 = (int64_t)blockIdx.x * RS_TILE;
+  const int count = (int)((n - tile0 < RS_TILE) ? (n - tile0) : RS_TILE);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) cnt[w][tid] = 0;
+  __syncthreads();
+  uint32_t key[RS_ROUNDS];
+  int32_t pos[RS_ROUNDS];
+  unsigned int loc[RS_ROUNDS];                   // rank among the wave's earlier keys of the same digit
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    const int e = wave * 512 + r * 64 + lane;
+    const bool ok = e < count;
+    key[r] = ok ? rs_key<FIRST>(ids, keys_in, tile0 + e) : 0u;
+    pos[r] = ok ? (FIRST ? (int32_t)(tile0 + e) : pos_in[tile0 + e]) : 0;
+  }
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    const int e = wave * 512 + r * 64 + lane;
+    const bool ok = e < count;
+    const uint32_t d = (key[r] >> shift) & dmask;
+    unsigned long long m = __ballot(ok);
+    for (int b = 0; b < dbits; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long bal = __ballot(bit);
+      m &= bit ? bal : ~bal;
+    }
+    // lanes of one digit read the counter (one address: broadcast), the lowest of them adds the group's size; LDS
+    // operations of a wave complete in program order, so the next round sees the sum
+    unsigned int old = 0;
+    if (ok) {
+      old = cnt[wave][d];
+      if ((m & lt) == 0) cnt[wave][d] = old + (unsigned int)__popcll(m);
+    }
+    loc[r] = old + (unsigned int)__popcll(m & lt);
+  }
+  __syncthreads();
+  {
+    const unsigned int c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid], c3 = cnt[3][tid];
+    const unsigned int dstart = rs_excl_scan_256(c0 + c1 + c2 + c3, wave_tot);      // digit's start inside the tile
+    const unsigned int dbase = rs_excl_scan_256(tot[tid], wave_tot);                // digit's start in the output
+    cnt[0][tid] = dstart;
+    cnt[1][tid] = dstart + c0;
+    cnt[2][tid] = dstart + c0 + c1;
+    cnt[3][tid] = dstart + c0 + c1 + c2;
+    gpos[tid] = dbase + hist[(int64_t)tid * n_tiles + blockIdx.x] - dstart;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    const int e = wave * 512 + r * 64 + lane;
+    if (e < count) {
+      const uint32_t d = (key[r] >> shift) & dmask;
+      const unsigned int s = cnt[wave][d] + loc[r];
+      st_key[s] = key[r];
+      st_pos[s] = pos[r];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < count; i += 256) {
+    const uint32_t k = st_key[i];
+    const unsigned int o = gpos[(k >> shift) & dmask] + (unsigned int)i;
+    keys_out[o] = k;
+    pos_out[o] = st_pos[i];
+  }
+}
+
+// keys_out / perm <- stable sort of ((uint32)ids[i], i) by the low `bits` key bits.  Only launches kernels.
+int radix_sort_ids(const int64_t* ids, int64_t n, unsigned bits, char* ws, const Layout& L, uint32_t* keys_out,
+                   int32_t* perm, hipStream_t st) {
+  const int n_tiles = (int)ceil_div64(n, RS_TILE);
+  uint32_t* keys_tmp = (uint32_t*)(ws + L.keys_tmp);
+  int32_t* pos_tmp = (int32_t*)(ws + L.pos_tmp);
+  uint32_t* hist = (uint32_t*)(ws + L.hist);
+  uint32_t* tot = (uint32_t*)(ws + L.tot);
+  if (bits < 1) bits = 1;
+  const int passes = (int)((bits + 7) / 8);
+  const int w = (int)((bits + passes - 1) / passes);
+  const uint32_t* kin = nullptr;
+  const int32_t* pin = nullptr;
+  for (int p = 0; p < passes; ++p) {
+    const int shift = p * w;
+    const int dbits = ((int)bits - shift < w) ? (int)bits - shift : w;
+    const uint32_t dmask = (1u << dbits) - 1u;
+    const bool to_out = ((passes - 1 - p) & 1) == 0;
+    uint32_t* kout = to_out ? keys_out : keys_tmp;
+    int32_t* pout = to_out ? perm : pos_tmp;
+    if (p == 0) {
+      hipLaunchKernelGGL((rs_hist_kernel<true>), dim3(n_tiles), dim3(256), 0, st, ids, kin, n, shift, dmask, n_tiles, hist);
+      REC_LAUNCH_CHECK();
+      hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_BINS), dim3(256), 0, st, hist, n_tiles, tot);
+      REC_LAUNCH_CHECK();
+      hipLaunchKernelGGL((rs_scatter_kernel<true>), dim3(n_tiles), dim3(256), 0, st, ids, kin, pin, n, shift, dbits,
+                         n_tiles, hist, tot, kout, pout);
+    } else {
+      hipLaunchKernelGGL((rs_hist_kernel<false>), dim3(n_tiles), dim3(256), 0, st, ids, kin, n, shift, dmask, n_tiles, hist);
+      REC_LAUNCH_CHECK();
+      hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_BINS), dim3(256), 0, st, hist, n_tiles, tot);
+      REC_LAUNCH_CHECK();
+      hipLaunchKernelGGL((rs_scatter_kernel<false>), dim3(n_tiles), dim3(256), 0, st, ids, kin, pin, n, shift, dbits,
+                         n_tiles, hist, tot, kout, pout);
+    }
+    REC_LAUNCH_CHECK();
+    kin = kout;
+    pin = pout;
+  }
+  return REC_OK;
 }
 
 __device__ __forceinline__ int block_sum_256(int v, int* sh) {
@@ -410,28 +587,12 @@ extern "C" int rec_dedup_plan_i64(const int64_t* ids, int64_t n, int64_t V, int6
   Layout L = make_layout(n);
   if (workspace_bytes < L.total) return REC_E_WORKSPACE;
   char* ws = (char*)workspace;
-  uint32_t* keys_in = (uint32_t*)(ws + L.keys_in);
   uint32_t* keys_out = (uint32_t*)(ws + L.keys_out);
-  int32_t* pos_in = (int32_t*)(ws + L.pos_in);
   int32_t* tile_heads = (int32_t*)(ws + L.tile_heads);
-  hipLaunchKernelGGL(prep_keys_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, st, ids, n, keys_in,
-                     pos_in);
-  REC_LAUNCH_CHECK();
   unsigned end_bit = 1;
   while (end_bit < 32 && (int64_t(1) << end_bit) < V) ++end_bit;
-  size_t tmp = L.sort_tmp_bytes;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  hipError_t e = hipStreamIsCapturing(st, &cap);
-  if (e != hipSuccess) return (int)e;
-  if (cap == hipStreamCaptureStatusActive && n >= MERGE_LARGE_N)
-    e = rocprim::radix_sort_pairs<MergeSortOnlyLarge>(ws + L.sort_tmp, tmp, keys_in, keys_out, pos_in, perm, (size_t)n,
-                                                      0u, end_bit, st);
-  else if (cap == hipStreamCaptureStatusActive)
-    e = rocprim::radix_sort_pairs<MergeSortOnly>(ws + L.sort_tmp, tmp, keys_in, keys_out, pos_in, perm, (size_t)n, 0u,
-                                                 end_bit, st);
-  else
-    e = rocprim::radix_sort_pairs(ws + L.sort_tmp, tmp, keys_in, keys_out, pos_in, perm, (size_t)n, 0u, end_bit, st);
-  if (e != hipSuccess) return (int)e;
+  int rc = radix_sort_ids(ids, n, end_bit, ws, L, keys_out, perm, st);
+  if (rc != REC_OK) return rc;
   int n_tiles = (int)ceil_div64(n, TILE);
   hipLaunchKernelGGL(count_heads_kernel, dim3(n_tiles), dim3(256), 0, st, keys_out, n, tile_heads);
   REC_LAUNCH_CHECK();

@@ -825,7 +825,11 @@ static int launch_fused(const float* table, int64_t ld, int64_t V, const int64_t
   int nwg = (int)ceil_div64(B, EX);
   float* dK0part = (float*)workspace;
   float* small = dK0part + (size_t)nwg * F * E16 * U1;
-  static const int stop = getenv("REC_FUSED_STOP") ? atoi(getenv("REC_FUSED_STOP")) : 0;   // diagnostics only
+#ifdef REC_DEBUG_PHASE_STOPS   // profiling builds only (scripts/exp/*_phases.sh): the kernel stops after phase N
+  static const int stop = getenv("REC_FUSED_STOP") ? atoi(getenv("REC_FUSED_STOP")) : 0;
+#else
+  constexpr int stop = 0;
+#endif
   FusedArgs a{table, V, bias, K0, b0, K1, b1, K2, b2, label, B, F, gz, vals, prob, dK0part, small, oob_flag, stop};
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(deepfm_fwd_bwd_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -781,7 +781,11 @@ extern "C" int rec_din_attn_fwd_f32(const float* embed, int64_t ld, int64_t V, i
   if ((act == DACT_DICE && (!alpha || !mean || !var)) || (act == DACT_PRELU && !alpha)) return REC_E_ARG;
   size_t lds = attn_lds_bytes(D, H, false);
   if (lds > 150 * 1024) return REC_E_UNSUPPORTED;
+#ifdef REC_DEBUG_PHASE_STOPS   // profiling builds only (scripts/exp/*_phases.sh): the kernel stops after phase N
   static const int din_stop = getenv("REC_DIN_STOP") ? atoi(getenv("REC_DIN_STOP")) : 0;
+#else
+  constexpr int din_stop = 0;
+#endif
   AttnArgs a{embed, ld, V, E, C, series, T, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index, mask_valid, din_stop};
 #define LAUNCH_FWD(NT)                                                                                            \
   do {                                                                                                            \
@@ -817,7 +821,11 @@ extern "C" int rec_din_attn_bwd_f32(const float* embed, int64_t ld, int64_t V, i
     return REC_E_ARG;
   size_t lds = attn_lds_bytes(D, H, true);
   if (lds > 150 * 1024) return REC_E_UNSUPPORTED;
+#ifdef REC_DEBUG_PHASE_STOPS   // profiling builds only (scripts/exp/*_phases.sh): the kernel stops after phase N
   static const int din_stop = getenv("REC_DIN_STOP") ? atoi(getenv("REC_DIN_STOP")) : 0;
+#else
+  constexpr int din_stop = 0;
+#endif
   AttnArgs a{embed, ld, V, E, C, series, T, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index, mask_valid, din_stop};
 #define LAUNCH_BWD(NT)                                                                                            \
   do {                                                                                                            \

@@ -201,6 +201,15 @@ def gemm(A, B, transA=False, transB=False, epi=EPI_NONE, bias=None, e0=None, e1=
         raise ValueError("gemm inner dimensions differ: %d vs %d" % (K, K2))
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    if out.dim() != 2 or tuple(out.shape) != (M, N) or out.stride(1) != 1 or out.dtype != torch.float32:
+        raise ValueError("out must be a 2-D fp32 [%d,%d] tensor with unit inner stride" % (M, N))
+    if aux is not None:
+        # the kernel writes U with C's leading dimension: a contiguous aux beside a column-slice `out` would be
+        # written out of bounds
+        if (tuple(aux.shape) != (M, N) or aux.dtype != torch.float32 or aux.stride(1) != 1
+                or aux.stride(0) != out.stride(0)):
+            raise ValueError("aux must be fp32 [%d,%d] with the same row stride as out (%d), got stride %s"
+                             % (M, N, out.stride(0), tuple(aux.stride())))
     if split_k is None:
         skinny = (not transA) and (not transB) and N <= 64 and M >= 256      # the no-LDS kernel splits K over its waves
         split_k = 1 if skinny else split_k_for(K, M, N)

@@ -110,8 +110,15 @@ def cross_vec(x0, ws, bs):
     return xl.squeeze(2)
 
 
-def cross_mat(x0, Ws, bs):
-    """MatrixCrossLayer.call, 3.DCN/CustomLayers.py:297-305."""
+def cross_mat(x0, Ws, bs, row_form=False):
+    """MatrixCrossLayer.call, 3.DCN/CustomLayers.py:297-305.  ``row_form``: the same numbers as U = X W^T on [B,D] rows
+     -- for config-size batches, where the literal broadcast matmul would expand W to [B,D,D]
+    (13.7 GB in fp64 at B = 16384, D = 323); tests/test_oracle.py holds the two forms equal."""
+    if row_form:
+        xl = x0
+        for W, b in zip(Ws, bs):
+            xl = x0 * (xl @ W.t() + b.reshape(1, -1)) + xl
+        return xl
     x0c = x0.unsqueeze(2)
     xl = x0c
     for W, b in zip(Ws, bs):
@@ -120,12 +127,12 @@ def cross_mat(x0, Ws, bs):
     return xl.squeeze(2)
 
 
-def dcn_forward(p, X, X_cont, kind="vec", sparse=False):
+def dcn_forward(p, X, X_cont, kind="vec", sparse=False, row_form=False):
     """DeepCrossNetworkLayer.call, 3.DCN/CustomLayers.py:239-269."""
     x_flat = lookup(p["embed"], X, sparse).flatten(1)
     _input = torch.cat([X_cont, x_flat], dim=1)
     cross = cross_vec(_input, p["cross_w"], p["cross_b"]) if kind == "vec" else \
-        cross_mat(_input, p["cross_w"], p["cross_b"])
+        cross_mat(_input, p["cross_w"], p["cross_b"], row_form)
     dnn = mlp(_input, p["dnn_k"], p["dnn_b"], "relu")
     comb = torch.cat([cross, dnn], dim=1)
     return torch.sigmoid(comb @ p["out_k"] + p["out_b"])
