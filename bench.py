@@ -202,14 +202,14 @@ def main():
 
     def run_steps(n):
         i = 0
-        if cycle:
+        if cycle:       # every call announces the batches of the NEXT call: their plans are built beside this call's steps
             while n - i >= Cy:
                 b0 = i % n_batches
-                step.many(batches[b0:b0 + Cy], then=batches[(b0 + Cy) % n_batches])
+                step.many(batches[b0:b0 + Cy], then=[batches[(b0 + Cy + j) % n_batches] for j in range(Cy)])
                 i += Cy
             if n - i > 0:                                        # ragged tail: one shorter graph
                 b0 = i % n_batches
-                step.many(batches[b0:b0 + n - i], then=batches[(b0 + n - i) % n_batches])
+                step.many(batches[b0:b0 + n - i], then=[batches[(b0 + n - i + j) % n_batches] for j in range(Cy)])
                 i = n
         while i < n:
             run(i)
@@ -260,7 +260,7 @@ def main():
             i = 0
             while (not args.no_graph) and n - i >= Cy:
                 b0 = i % n_batches
-                rstep.many(batches[b0:b0 + Cy], then=batches[(b0 + Cy) % n_batches])
+                rstep.many(batches[b0:b0 + Cy], then=[batches[(b0 + Cy + j) % n_batches] for j in range(Cy)])
                 i += Cy
             while i < n:
                 rstep(batches[i % n_batches], next_inputs=batches[(i + 1) % n_batches])
@@ -344,23 +344,23 @@ def main():
         # above + labels + dL/dz + the IndexedSlices values it writes.
         fused_bytes = gather_bytes + B * 4 + B * 4 + B * F * E * 4
         fs = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, optimizer=None, use_graph=False)
-        arrs = [(C.c_void_p * F)(*[b[k].data_ptr() for k in names]) for b in batches]
-        L, g = layer, fs.g
+        colss = [fs._cols(b) for b in batches]
+        assert n_batches <= fs.NBUF
+        for i in range(n_batches):                    # the plans exist before the kernel runs (direct mode), as in a step
+            fs._sort(colss[i], i, torch.cuda.current_stream())
+        torch.cuda.synchronize()
 
         def launch_fused(n):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             for i in range(n):
-                check(lib.rec_deepfm_fused_main_f32(
-                    vp(emb), emb.stride(0), V, arrs[i % n_batches], F, B, vp(L.bias), vp(L.MLP_layer1.kernel_0),
-                    vp(L.MLP_layer1.bias_0), vp(L.MLP_layer1.kernel_1), vp(L.MLP_layer1.bias_1),
-                    vp(L.MLP_layer2.kernel_0), vp(L.MLP_layer2.bias_0), vp(batches[i % n_batches]["label"]), vp(fs.gz),
-                    vp(fs.vals), None, vp(fs.oob), vp(fs.ws), st), "rec_deepfm_fused_main_f32")
+                fs._launch_main(colss[i % n_batches], batches[i % n_batches]["label"], st, i % n_batches)
 
-        roofline = roof("deepfm_fwd_bwd_kernel (gather, FM, MLP on fp32 MFMA, BCE, backward, IndexedSlices values; its "
-                        "workgroup partials are reduced in the next launch)", fused_bytes, timed(launch_fused, 50),
-                        ["deepfm_fwd_bwd_kernel"],
-                        "latency/sync-bound at one 134-KB workgroup per CU; 0.65 GFLOP of fp32 MFMA per launch is ~1% of "
-                        "the matrix peak, so HBM is the binding roofline")
+        roofline = roof("deepfm_fwd_bwd_kernel<direct> (gather, FM, MLP on fp32 MFMA, BCE, backward, IndexedSlices values "
+                        "written to their de-duplicated slots; its workgroup partials are reduced in the next launch)",
+                        fused_bytes, timed(launch_fused, 48), ["deepfm_fwd_bwd_kernel"],
+                        "one 8-wave workgroup (32 examples) per CU: a dependent chain ids -> rows (random 128-B lines, "
+                        "~31 G lines/s chip-wide) -> head -> backward with nothing to overlap it at 32 examples per CU; "
+                        "0.65 GFLOP of fp32 MFMA per launch is ~1% of the matrix peak, so HBM is the binding roofline")
 
     extra = {}
     if args.adam_steps > 0 and rank == 0:
@@ -396,8 +396,9 @@ def main():
                           "of unique ids, owner gather, all-to-all of rows, fused fwd+bwd on them, per-id sums, all-to-all "
                           "of row gradients, owner rank-merge" if sharded_mode else
                           "generic" if args.generic else
-                          "fused: fwd+bwd kernel, then reduction + segment sums in one launch; de-duplication plan of "
-                          "batch k+1 (per-column sort, second stream) overlaps step k"},
+                          "fused: fwd+bwd kernel writing value rows straight to their de-duplicated slots (plan complete "
+                          "before the kernel), then reduction + remaining segment sums in one launch; de-duplication "
+                          "plan of batch k+1 (per-column sort, second stream) overlaps step k"},
                "roofline": roofline, "roofline_gather": roofline_gather, "loss": loss}
         if replicas is not None:
             out["replicas_no_exchange"] = replicas

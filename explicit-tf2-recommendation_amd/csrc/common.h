@@ -27,3 +27,20 @@ __device__ __forceinline__ float group_sum(float v) {
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 // accurate form used where parity at 1e-6 matters (logits can be large)
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane, by four v_add_f32 with DPP operands
+// (quad_perm xor 1, quad_perm xor 2, row_half_mirror, row_mirror) instead of four ds_bpermute round trips.  After the
+// two quad steps every lane of a quad holds the quad's sum, so the mirror steps pair lanes that hold the SAME partial
+// on each side: all 16 lanes end with bit-identical sums (a + b == b + a).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_allsum(float v) {
+  v += dpp_mov_f32<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_mov_f32<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_mov_f32<0x141>(v);    // row_half_mirror: lane i <-> 7 - i inside each half row
+  v += dpp_mov_f32<0x140>(v);    // row_mirror: lane i <-> 15 - i
+  return v;
+}
+

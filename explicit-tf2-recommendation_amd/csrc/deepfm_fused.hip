@@ -27,7 +27,6 @@
 // Everything is deterministic (no float atomics): per-workgroup partials + fixed-order reductions, stable sort keys.
 #include "common.h"
 #include <math.h>
-#include <stdlib.h>
 
 namespace {
 
@@ -38,8 +37,11 @@ constexpr int EX = 32;        // examples per workgroup
 constexpr int E16 = 16;       // embedding dims
 constexpr int LD = 32;        // fused row stride (floats)
 constexpr int U1 = 32, U2 = 8;
-constexpr int HS = 33;        // padded row stride of the [*,32] LDS tiles
 constexpr int SMALL = 320;    // floats of small partials per workgroup
+constexpr int NWV = 8;        // waves per workgroup (512 threads: two waves per SIMD, one workgroup per CU)
+constexpr int MAXFW = 4;      // fields per wave (F <= 28 over 8 waves)
+constexpr int HSP = 34;       // row stride of a wave's partial layer-1 tile (even: float2 reads)
+constexpr int HS1 = 36;       // row stride of H1s / DP1 (16-byte aligned rows: ds_read_b128 operand fetches)
 
 struct Cols {
   const int64_t* p[REC_MAX_COLS];
@@ -60,341 +62,460 @@ struct FusedArgs {
   float* dK0part;             // [nwg, F*16*32]
   float* small;               // [nwg, SMALL]
   int* oob;
-  int stop;                   // diagnostics only (REC_FUSED_STOP): leave after phase `stop` (0 = run everything)
+  // direct mode (the batch's plan exists before the launch): a lookup that heads its run of equal ids writes its value
+  // row straight to the run's slot of the de-duplicated gradient; only the other members of a run go through `vals`
+  const int32_t* dloc;        // [F,B] column-local run index of lookup (f,b); sign bit set = not the head of its run
+  const int32_t* col_nu;      // [F]   runs per column
+  float* g_embed;             // [B*F,16] de-duplicated row sums
+  float* g_w;                 // [B*F]    ... of the first-order table
+  int64_t* uniq_ids;          // [B*F]    the id of every slot
+#ifdef REC_FUSED_STAMPS
+  unsigned long long* stamps; // diagnostic build only: [nwg][8 waves][12] s_memrealtime ticks (10 ns)
+#endif
 };
 
-__device__ __forceinline__ int xs_of(int F) { return F * E16 + 2; }
+#ifdef REC_FUSED_STAMPS
+#define STAMP(k)                                                                                   \
+  do {                                                                                             \
+    if (lane == 0) a.stamps[((int64_t)blockIdx.x * NWV + wave) * 12 + (k)] = wall_clock64();       \
+  } while (0)
+// diagnostic only: drain the wave's memory queues first, so that the stamp reads "everything issued so far is back"
+#define STAMP_DRAINED(k)                                              \
+  do {                                                                \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       \
+    STAMP(k);                                                         \
+  } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#define STAMP_DRAINED(k) do {} while (0)
+#endif
 
-__global__ __launch_bounds__(256) void deepfm_fwd_bwd_kernel(Cols cols, FusedArgs a) {
-  extern __shared__ float lds[];
+// row stride of the gathered-rows tile: 16F + 4.  (16F + 4)/4 is odd, so the 16-byte operand fetches of 16 lanes with
+// distinct rows (mod 16) fall on distinct bank quads, and rows 4 apart sit 16 banks apart (the 32-lane halves of the
+// transposed reads in the backward phases are conflict-free)
+__device__ __forceinline__ int xs_of(int F) { return F * E16 + 4; }
+
+// LDS carve (floats); everything in ONE dynamic array
+struct Carve {
+  int XT, PT, SP, SQ, WP, H1s, DP1, Ss, h2s, dp2s, zfm, dzs, lss, K1s, b0s, b1s, K2s, total;
+};
+__host__ __device__ inline Carve carve_of(int F) {
+  Carve c;
+  int o = 0;
+  c.XT = o; o += EX * (F * E16 + 4);
+  c.PT = o; o += NWV * EX * HSP;
+  c.SP = o; o += NWV * EX * E16;
+  c.SQ = o; o += NWV * EX * 2;
+  c.WP = o; o += NWV * EX;
+  c.H1s = o; o += EX * HS1;
+  c.DP1 = o; o += EX * HS1;
+  c.Ss = o; o += EX * E16;
+  c.h2s = o; o += EX * U2;
+  c.dp2s = o; o += EX * U2;
+  c.zfm = o; o += EX;
+  c.dzs = o; o += EX;
+  c.lss = o; o += EX;
+  c.K1s = o; o += U1 * U2;
+  c.b0s = o; o += U1;
+  c.b1s = o; o += U2;
+  c.K2s = o; o += U2;
+  c.total = o;
+  return c;
+}
+
+// One workgroup = 32 examples, 8 waves.  Wave w OWNS fields w, w+8, w+16, w+24 from the first id load to the last store:
+//
+//   A  (no barrier inside) the wave loads its fields' ids, issues all its row loads (16-byte pieces, 8 lanes per 128-byte
+//      fused row) and its slice of K0 (straight from L2 into MFMA B fragments), then field by field as the rows arrive:
+//      rows -> LDS tile XT, first-order weights summed in registers, the A fragments of that field read back
+//      (lane = example: two 16-byte LDS reads), FM sums, 8 x v_mfma_f32_32x32x2_f32 into the wave's partial layer-1 tile.
+//      The layer-1 product and the FM sums therefore run UNDER the gather instead of after it.
+//   B  the 8 partial tiles / FM partials meet in LDS (barrier), 512 threads finish layer 1, the 32->8->1 head, sigmoid,
+//      Keras BCE and their backward (two barriers).
+//   C  (no barrier inside) per owned field, on v_mfma_f32_16x16x4_f32 tiles (one field = 16 columns, so the 26 fields
+//      spread 7/7/6/6 over the four SIMDs): dX = dpre1 . K0_f^T with the IndexedSlices values dz*(S - x) + dX stored as
+//      64-byte rows, and the workgroup's partial of dK0_f = X_f^T . dpre1.  K0_f comes from L2 as two 16-byte loads per
+//      lane, the operands made of dpre1 stay in registers for all fields.
+// K0 never sits in LDS (the 53 KB copy per workgroup of round 1 is gone); LDS holds the rows once (54 KB) + ~60 KB of
+// exchange buffers.
+template <bool DIRECT>
+__global__ __launch_bounds__(512) void deepfm_fwd_bwd_kernel(Cols cols, FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int F = a.F, D = F * E16, XS = xs_of(F);
-  float* XT = lds;                       // [EX][XS]      gathered embedding rows (later: dK0 exchange scratch)
-  float* K0s = XT + EX * XS;             // [D][HS]
-  float* H1s = K0s + D * HS;             // [EX][HS]      relu(h1)
-  float* DP1 = H1s + EX * HS;            // [EX][HS]      d pre-activation of layer 1
-  float* Ss = DP1 + EX * HS;             // [EX][16]
-  // ids (P0-P1) and the first-order weights Wl (P1-P2) are dead before H1s / DP1 are first written (P3, P4):
-  // they share that region (2*EX*F <= 2*EX*HS for F <= 33), which keeps the workgroup at ~134 KB of LDS so that a
-  // 32-KB sort workgroup of the second stream can be co-resident on the CU
-  float* Wl = H1s;                       // [EX*F]
-  int* ids = reinterpret_cast<int*>(H1s + EX * F);   // [EX*F]
-  float* h2s = Ss + EX * E16;            // [EX][8]
-  float* dp2s = h2s + EX * U2;           // [EX][8]
-  float* zfm = dp2s + EX * U2;           // [EX]
-  float* dzs = zfm + EX;                 // [EX]
-  float* lss = dzs + EX;                 // [EX]
-  float* K1s = lss + EX;                 // [32][8]
-  float* b0s = K1s + U1 * U2;            // [32]
-  float* b1s = b0s + U1;                 // [8]
-  float* K2s = b1s + U2;                 // [8]
-  float* PT = K2s + U2;                  // [4 waves][EX][HS]  K-split partial tiles of layer 1 (P3)
+  const Carve cv = carve_of(F);
+  float* XT = lds + cv.XT;               // [EX][XS]
+  float* PT = lds + cv.PT;               // [8][EX][HSP]   partial layer-1 tiles
+  float* SP = lds + cv.SP;               // [8][EX][16]    partial sums of e over the wave's fields
+  float* SQ = lds + cv.SQ;               // [8][EX][2]     partial sums of e^2 (lane halves)
+  float* WP = lds + cv.WP;               // [8][EX]        partial first-order sums
+  float* H1s = lds + cv.H1s;             // [EX][HS1]      relu(h1)
+  float* DP1 = lds + cv.DP1;             // [EX][HS1]      d pre-activation of layer 1
+  float* Ss = lds + cv.Ss;               // [EX][16]
+  float* h2s = lds + cv.h2s;             // [EX][8]
+  float* dp2s = lds + cv.dp2s;           // [EX][8]
+  float* zfm = lds + cv.zfm;
+  float* dzs = lds + cv.dzs;
+  float* lss = lds + cv.lss;
+  float* K1s = lds + cv.K1s;             // [32][8]
+  float* b0s = lds + cv.b0s;
+  float* b1s = lds + cv.b1s;
+  float* K2s = lds + cv.K2s;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // scalar: field ownership is wave-uniform
   const int64_t ex0 = (int64_t)blockIdx.x * EX;
   const int n_ex = (a.B - ex0 < EX) ? (int)(a.B - ex0) : EX;
-
-  // ---- P0: K0 (53 KB, the same for every workgroup) starts its trip from L2 into registers first, so that its
-  // latency hides behind the id fetch and the row gather; ids of the 32 examples from the F feature columns go to
-  // LDS as ids[f*32 + e] (one field per gather pass: no integer division anywhere)
-  constexpr int MAXK = 14;                                   // F <= 28: D*8/256 = F/2 float4 per thread
-  float4 kreg[MAXK];
-#pragma unroll
-  for (int q = 0; q < MAXK; ++q) {
-    int i = tid + q * 256;
-    kreg[q] = i < D * (U1 / 4) ? reinterpret_cast<const float4*>(a.K0)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  bool bad = false;
-  for (int i = tid; i < EX * F; i += 256) {
-    int f = i >> 5, e = i & 31;              // consecutive threads read consecutive examples of one column
-    int v = -1;
-    if (e < n_ex) {
-      int64_t id = cols.p[f][ex0 + e];
-      if ((uint64_t)id < (uint64_t)a.V) v = (int)id; else bad = true;
-    }
-    ids[i] = v;
-  }
-  if (bad && a.oob) *a.oob = 1;
-  K1s[tid] = a.K1[tid];
-  if (tid < U1) b0s[tid] = a.b0[tid];
-  if (tid < U2) { b1s[tid] = a.b1[tid]; K2s[tid] = a.K2[tid]; }
-  __syncthreads();
-  if (a.stop == 1) return;
-
-  // ---- P1: gather.  8 lanes x 16 B cover one 128-B row; pass `it` = field it of the 32 examples; every pass's
-  // load is issued before anything is consumed (F independent 16-B loads in flight per lane)
-  {
-    const int c = tid & 7, e = tid >> 3;
-    constexpr int MAXP = 28;
-    float4 v[MAXP];
-#pragma unroll
-    for (int it = 0; it < MAXP; ++it) {
-      v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (it < F && c <= 4) {
-        int id = ids[it * 32 + e];
-        if (id >= 0) v[it] = *reinterpret_cast<const float4*>(a.table + (int64_t)id * LD + 4 * c);
-      }
-    }
-    // K0 registers -> LDS (rows of 33 floats) while the rows are in flight
-#pragma unroll
-    for (int q = 0; q < MAXK; ++q) {
-      int i = tid + q * 256;
-      if (i < D * (U1 / 4)) {
-        float* dst = K0s + (i >> 3) * HS + (i & 7) * 4;
-        dst[0] = kreg[q].x; dst[1] = kreg[q].y; dst[2] = kreg[q].z; dst[3] = kreg[q].w;
-      }
-    }
-    float* xrow = XT + e * XS + 4 * c;                       // 8-byte aligned only (XS even): two 8-byte stores
-#pragma unroll
-    for (int it = 0; it < MAXP; ++it) {
-      if (it < F) {
-        if (c < 4) {
-          float* dst = xrow + it * E16;
-          reinterpret_cast<float2*>(dst)[0] = make_float2(v[it].x, v[it].y);
-          reinterpret_cast<float2*>(dst)[1] = make_float2(v[it].z, v[it].w);
-        } else if (c == 4) {
-          Wl[it * 32 + e] = v[it].x;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (a.stop == 2) return;
-
-  // ---- P2: FM terms.  thread = (example e, dim pair d2)
-  {
-    const int e = tid >> 3, d2 = tid & 7;
-    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-    const float* xr = XT + e * XS + 2 * d2;
-    for (int f = 0; f < F; ++f) {
-      float2 x = *reinterpret_cast<const float2*>(xr + f * E16);
-      s0 += x.x; s1 += x.y;
-      q0 += x.x * x.x; q1 += x.y * x.y;
-    }
-    Ss[e * E16 + 2 * d2] = s0;
-    Ss[e * E16 + 2 * d2 + 1] = s1;
-    float part = (s0 * s0 - q0) + (s1 * s1 - q1);
-    part += __shfl_xor(part, 1, 64);
-    part += __shfl_xor(part, 2, 64);
-    part += __shfl_xor(part, 4, 64);
-    if (d2 == 0) {
-      float first = 0.f;
-      for (int f = 0; f < F; ++f) first += Wl[f * 32 + e];
-      zfm[e] = a.bias[0] + first + 0.5f * part;
-    }
-  }
-  __syncthreads();                         // Wl / ids are dead from here on: their LDS becomes H1s / DP1
-  if (a.stop == 3) return;
-
-  // ---- P3: h1 = relu(X . K0 + b0) on the matrix cores, 32x32x2 tiles.  The output is ONE 32x32 tile, so the four
-  // waves split K = 16F: wave w multiplies columns [4F*w, 4F*(w+1)) of X with the matching rows of K0 (2F steps of 2),
-  // the four partial tiles meet in LDS and are added in wave order.  Lane l: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];
-  // D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
   const int lo = lane & 31, hi = lane >> 5;
+
+  // scalars and labels of phase B: loaded now, their HBM latency hides behind phase A
+  const float bias_r = a.bias[0], b2_r = a.b2[0];
+  const float inv_B = 1.f / (float)a.B;
+  const float label_r = ((tid >> 4) < n_ex) ? a.label[ex0 + (tid >> 4)] : 0.f;
+
+  // ================================================ phase A ======================================================
+  STAMP(0);
   {
+    // ids first (they head the longest dependent chain of the kernel): lane = (piece c of the row, example e' of the
+    // group of 8); slot g = examples 8g + e'
+    const int c = lane & 7, ep = lane >> 3;
+    // every id load is issued unconditionally (clamped address) and only then checked: a load inside a guarded
+    // block would be waited for before the next one is issued
+    int64_t idr[MAXFW][4];
+#pragma unroll
+    for (int i = 0; i < MAXFW; ++i) {
+      const int f = wave + NWV * i;
+      const int64_t* col = cols.p[f < F ? f : F - 1];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int e = 8 * g + ep;
+        idr[i][g] = col[ex0 + (e < n_ex ? e : n_ex - 1)];
+      }
+    }
+    STAMP_DRAINED(8);                           // (diagnostic builds) the ids are here
+    // rows: every load of the wave is issued before anything is consumed; an invalid lookup reads row 0 and is
+    // zeroed afterwards, lanes c > 4 repeat the address of lane 4 (same request)
+    bool ok[MAXFW][4];
+    bool bad = false;
+    float4 v[MAXFW][4];
+    const int cc = c < 4 ? c : 4;
+#pragma unroll
+    for (int i = 0; i < MAXFW; ++i) {
+      const int f = wave + NWV * i;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const bool live = f < F && 8 * g + ep < n_ex;
+        const bool inr = (uint64_t)idr[i][g] < (uint64_t)a.V;
+        bad |= live && !inr;
+        ok[i][g] = live && inr;
+        const int64_t row = ok[i][g] ? idr[i][g] : 0;
+        v[i][g] = *reinterpret_cast<const float4*>(a.table + row * LD + 4 * cc);
+      }
+    }
+    // K0 slice of the owned fields as B fragments of the 32x32x2 product: step s of field i multiplies the row's dims
+    // 8*hi + s (the k slot of a lane is its half), so B[k slot hi][unit lo] = K0[f*16 + 8*hi + s][lo]: two 128-byte
+    // segments per wave instruction, L2-resident
+    float kb[MAXFW][8];
+#pragma unroll
+    for (int i = 0; i < MAXFW; ++i) {
+      const int f = wave + NWV * i;
+      if (f < F) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) kb[i][s] = a.K0[(f * E16 + 8 * hi + s) * U1 + lo];
+      }
+    }
+    if (bad && a.oob) *a.oob = 1;
+    STAMP(1);                                   // ids have arrived, every row load is issued
+    // small dense operands of phase B (first read after barrier 1)
+    if (tid < U1 * U2) K1s[tid] = a.K1[tid];
+    if (tid < U1) b0s[tid] = a.b0[tid];
+    if (tid < U2) { b1s[tid] = a.b1[tid]; K2s[tid] = a.K2[tid]; }
+#pragma unroll
+    for (int i = 0; i < MAXFW; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (!ok[i][g]) v[i][g] = make_float4(0.f, 0.f, 0.f, 0.f);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int kbeg = wave * 4 * F;
-    const float* ap = XT + lo * XS + kbeg + hi;              // + 2*step
-    const float* bp = K0s + (kbeg + hi) * HS + lo;           // + 2*step*HS
-    const int ns = 2 * F;                                    // steps of this wave
-    // groups of 4 steps, software-pipelined with a STATIC number of LDS loads in flight (no guarded loads: a guard
-    // makes the count of outstanding loads unknown to the compiler, which then waits for all of them before the
-    // first MFMA of every group); the last group and the 2-step tail of an odd F are peeled
-    const int ng = ns >> 2;
-    float ac[4], bc[4];
+    float sx[8], sq = 0.f, wacc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { ac[u] = ap[2 * u]; bc[u] = bp[2 * u * HS]; }      // F >= 2: group 0 exists
-    for (int gi = 0; gi + 1 < ng; ++gi) {
-      float an[4], bn[4];
+    for (int j = 0; j < 8; ++j) sx[j] = 0.f;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        an[u] = ap[2 * (4 * (gi + 1) + u)];
-        bn[u] = bp[2 * (4 * (gi + 1) + u) * HS];
+    for (int i = 0; i < MAXFW; ++i) {
+      const int f = wave + NWV * i;
+      if (f < F) {                                                    // wave-uniform
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (c < 4) *reinterpret_cast<float4*>(XT + (8 * g + ep) * XS + f * E16 + 4 * c) = v[i][g];
+          else if (c == 4) wacc[g] += v[i][g].x;
+        }
+        // the same wave reads the field back example-major: LDS operations of one wave complete in program order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float4 x0 = *reinterpret_cast<const float4*>(XT + lo * XS + f * E16 + 8 * hi);
+        const float4 x1 = *reinterpret_cast<const float4*>(XT + lo * XS + f * E16 + 8 * hi + 4);
+        const float xa[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          sx[s] += xa[s];
+          sq += xa[s] * xa[s];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s], kb[i][s], acc, 0, 0, 0);
+        }
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u], acc, 0, 0, 0);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { ac[u] = an[u]; bc[u] = bn[u]; }
     }
-    if (ng > 0) {
+    float* pt = PT + wave * (EX * HSP);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u], acc, 0, 0, 0);
-    }
-    for (int sn = 4 * ng; sn < ns; ++sn)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * sn], bp[2 * sn * HS], acc, 0, 0, 0);
-    float* pt = PT + wave * (EX * HS);
+    for (int r = 0; r < 16; ++r) pt[((r & 3) + 8 * (r >> 2) + 4 * hi) * HSP + lo] = acc[r];
+    float* sp = SP + (wave * EX + lo) * E16 + 8 * hi;
+    *reinterpret_cast<float4*>(sp) = make_float4(sx[0], sx[1], sx[2], sx[3]);
+    *reinterpret_cast<float4*>(sp + 4) = make_float4(sx[4], sx[5], sx[6], sx[7]);
+    SQ[(wave * EX + lo) * 2 + hi] = sq;
+    if (c == 4) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) pt[((r & 3) + 8 * (r >> 2) + 4 * hi) * HS + lo] = acc[r];
-  }
-  __syncthreads();
-  {
-    const int e = tid >> 3, u4 = (tid & 7) * 4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      int o = e * HS + u4 + q;
-      float h = ((PT[o] + PT[EX * HS + o]) + PT[2 * EX * HS + o]) + PT[3 * EX * HS + o];     // wave order: fixed
-      H1s[o] = fmaxf(h + b0s[u4 + q], 0.f);
+      for (int g = 0; g < 4; ++g) WP[wave * EX + 8 * g + ep] = wacc[g];
     }
   }
+  STAMP(2);                                     // rows consumed, partial tile written
   __syncthreads();
-  if (a.stop == 4) return;
+  STAMP(3);
 
-  // ---- P4: layers 32->8->1, sigmoid, Keras BCE and their backward.  thread = (example e, unit u)
+  // ================================================ phase B ======================================================
+  // 16 lanes per example; lane g16 owns units 2*g16, 2*g16+1 of layer 1.  Everything between the end of layer 1 and
+  // dpre1 stays inside the 16-lane group (xor butterflies: every lane ends up with bit-identical sums), so the whole
+  // head -- 32->8->1, sigmoid, Keras BCE and the way back -- needs no barrier of its own.
+  const int e16 = tid >> 4, g16 = tid & 15;
+  // first field's K0 fragments of phase C: requested now, back long before barrier 2
+  const int cj = lane & 15, cq = lane >> 4;
+  float4 kt0, kt1;
   {
-    const int e = tid >> 3, u = tid & 7;
-    const bool valid = e < n_ex;
-    float h2 = b1s[u];
+    const float* kp = a.K0 + ((wave < F ? wave : 0) * E16 + cj) * U1 + 8 * cq;
+    kt0 = *reinterpret_cast<const float4*>(kp);
+    kt1 = *reinterpret_cast<const float4*>(kp + 4);
+  }
+  // direct mode: slot of every (example, owned field) value row.  Column-local run index + runs in the columns before
+  int dl[MAXFW][2];
+  if (DIRECT) {
+    int run = 0;                                             // scalar prefix over col_nu (F <= 28 scalar loads)
+    int before[MAXFW] = {0, 0, 0, 0};
+    for (int q = 0; q < F; ++q) {
 #pragma unroll
-    for (int k = 0; k < U1; ++k) h2 += H1s[e * HS + k] * K1s[k * U2 + u];
-    h2 = fmaxf(h2, 0.f);
-    float dnn = h2 * K2s[u];
-    dnn += __shfl_xor(dnn, 1, 64);
-    dnn += __shfl_xor(dnn, 2, 64);
-    dnn += __shfl_xor(dnn, 4, 64);
-    float z = zfm[e] + dnn + a.b2[0];
-    float p = sigmoid_acc(z);
-    float y = valid ? a.label[ex0 + e] : 0.f;
-    const float eps = 1e-7f;
-    float pc = fminf(fmaxf(p, eps), 1.f - eps);
-    float le = -(y * logf(pc + eps) + (1.f - y) * logf(1.f - pc + eps));
-    float inside = (p >= eps && p <= 1.f - eps) ? 1.f : 0.f;
-    float dz = -(y / (pc + eps) - (1.f - y) / (1.f - pc + eps)) * inside * p * (1.f - p) / (float)a.B;
-    if (!valid) { dz = 0.f; le = 0.f; }
-    float dp2 = h2 > 0.f ? dz * K2s[u] : 0.f;
-    float dh1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int uu = 0; uu < U2; ++uu) {
-      float vv = __shfl(dp2, (lane & ~7) | uu, 64);
-#pragma unroll
-      for (int kq = 0; kq < 4; ++kq) dh1[kq] += vv * K1s[(4 * u + kq) * U2 + uu];
+      for (int i = 0; i < MAXFW; ++i)
+        if (q == wave + NWV * i) before[i] = run;
+      run += a.col_nu[q];
     }
 #pragma unroll
-    for (int kq = 0; kq < 4; ++kq) {
-      int k = 4 * u + kq;
-      DP1[e * HS + k] = H1s[e * HS + k] > 0.f ? dh1[kq] : 0.f;
-    }
-    h2s[e * U2 + u] = h2;
-    dp2s[e * U2 + u] = dp2;
-    if (u == 0) {
-      dzs[e] = dz;
-      lss[e] = le;
-      if (valid) {
-        a.gz[ex0 + e] = dz;
-        if (a.prob) a.prob[ex0 + e] = p;
+    for (int i = 0; i < MAXFW; ++i) {
+      const int f = wave + NWV * i;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int e = 16 * m + cj;
+        const bool live = f < F && e < n_ex;
+        int d = live ? a.dloc[(int64_t)f * a.B + ex0 + e] : -1;
+        dl[i][m] = d >= 0 ? d + before[i] : d;               // heads: global slot; others keep the sign bit
       }
     }
   }
-  __syncthreads();
-
-  // ---- small per-workgroup partials (fixed order over the 32 examples).  The single-thread sums are spread over the
-  // four waves (no barrier follows: a wave goes on to P5 as soon as its own share is stored)
   {
-    float* sm = a.small + (int64_t)blockIdx.x * SMALL;
-    const int k = tid >> 3, u = tid & 7;
-    float s = 0.f;
-#pragma unroll 8
-    for (int e = 0; e < EX; ++e) s += H1s[e * HS + k] * dp2s[e * U2 + u];
-    sm[tid] = s;                                             // dK1 [32][8]
-    if (wave == 1 && lane < U1) {
-      float t = 0.f;
-#pragma unroll 8
-      for (int e = 0; e < EX; ++e) t += DP1[e * HS + lane];
-      sm[256 + lane] = t;                                    // db0
+    // layer 1: the 8 partial tiles are added in wave order (fixed), + bias, relu
+    float2 h = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) {
+      const float2 p = *reinterpret_cast<const float2*>(PT + w * (EX * HSP) + e16 * HSP + 2 * g16);
+      h.x += p.x; h.y += p.y;
     }
-    if (wave == 2 && lane < U2) {
-      float t1 = 0.f, t2 = 0.f;
-#pragma unroll 8
-      for (int e = 0; e < EX; ++e) { t1 += dp2s[e * U2 + lane]; t2 += h2s[e * U2 + lane] * dzs[e]; }
-      sm[288 + lane] = t1;                                   // db1
-      sm[296 + lane] = t2;                                   // dK2
-    }
-    if (wave == 3 && lane == 0) {
-      float t1 = 0.f, t2 = 0.f;
-#pragma unroll 8
-      for (int e = 0; e < EX; ++e) { t1 += dzs[e]; t2 += lss[e]; }
-      sm[304] = t1;                                          // db2 = dbias
-      sm[305] = t2;                                          // sum of per-example BCE terms
-    }
-  }
-
-  if (a.stop == 5) return;
-
-  // ---- P5: dX = dpre1 . K0^T on the matrix cores, fused with the IndexedSlices values.  N = 16F is cut into tiles of
-  // 32 columns = two fields; wave w takes tiles w, w+4, ...; K = 32 units = 16 steps.  A (dpre1, the same for every
-  // tile) stays in registers.  D rows are examples, columns 32 consecutive floats of the example's values row: every
-  // accumulator register leaves as two full 128-byte lines, no transpose.
-  const int n_tiles = (F + 1) / 2;
-  {
-    float av[16], dzr[16], sr[16];
+    const float h1a = fmaxf(h.x + b0s[2 * g16], 0.f), h1b = fmaxf(h.y + b0s[2 * g16 + 1], 0.f);
+    H1s[e16 * HS1 + 2 * g16] = h1a;                       // kept for the dK1 partial of phase C
+    H1s[e16 * HS1 + 2 * g16 + 1] = h1b;
+    // FM: S_d (lane = dim), sum of squares and first order (one partial per lane), reduced over the 16 lanes
+    float sd = 0.f;
 #pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2) av[s2] = DP1[lo * HS + 2 * s2 + hi];
+    for (int w = 0; w < NWV; ++w) sd += SP[(w * EX + e16) * E16 + g16];
+    Ss[e16 * E16 + g16] = sd;
+    float t = sd * sd - SQ[((g16 >> 1) * EX + e16) * 2 + (g16 & 1)];
+    float fo = g16 < NWV ? WP[g16 * EX + e16] : 0.f;
+    // layer 2 (32 -> 8): this lane's two units times K1, then the same butterfly
+    float h2[U2];
+    {
+      const float4 ka0 = *reinterpret_cast<const float4*>(K1s + (2 * g16) * U2);
+      const float4 ka1 = *reinterpret_cast<const float4*>(K1s + (2 * g16) * U2 + 4);
+      const float4 kb0 = *reinterpret_cast<const float4*>(K1s + (2 * g16 + 1) * U2);
+      const float4 kb1 = *reinterpret_cast<const float4*>(K1s + (2 * g16 + 1) * U2 + 4);
+      h2[0] = h1a * ka0.x + h1b * kb0.x; h2[1] = h1a * ka0.y + h1b * kb0.y;
+      h2[2] = h1a * ka0.z + h1b * kb0.z; h2[3] = h1a * ka0.w + h1b * kb0.w;
+      h2[4] = h1a * ka1.x + h1b * kb1.x; h2[5] = h1a * ka1.y + h1b * kb1.y;
+      h2[6] = h1a * ka1.z + h1b * kb1.z; h2[7] = h1a * ka1.w + h1b * kb1.w;
+      t = row16_allsum(t);
+      fo = row16_allsum(fo);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int e = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      dzr[r] = dzs[e];
-      sr[r] = Ss[e * E16 + (lo & 15)];
-    }
-    for (int t = wave; t < n_tiles; t += 4) {
-      const float* bp = K0s + (t * 32 + lo) * HS + hi;       // B[k = unit 2s+hi][n = lo] = K0[t*32 + lo][2s + hi]
-      const float* xp = XT + (4 * hi) * XS + t * 32 + lo;    // x of (row r, this lane): + ((r&3) + 8*(r>>2)) * XS
-      f32x16 acc;
+      for (int u = 0; u < U2; ++u) h2[u] = row16_allsum(h2[u]);
+      float dnn = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      float bv[16], xv[16];
+      for (int u = 0; u < U2; ++u) {
+        h2[u] = fmaxf(h2[u] + b1s[u], 0.f);
+        dnn += h2[u] * K2s[u];
+      }
+      const bool valid = e16 < n_ex;
+      const float z = (bias_r + fo + 0.5f * t) + dnn + b2_r;
+      const float p = sigmoid_acc(z);
+      const float y = valid ? label_r : 0.f;
+      const float eps = 1e-7f;
+      const float pc = fminf(fmaxf(p, eps), 1.f - eps);
+      // v_log_f32 / v_rcp_f32 (1 ulp) instead of the library logf and IEEE divisions: the head runs on every wave of
+      // the workgroup and is bound by instruction issue; the results stay ~1e-7 relative from the exact ones
+      float le = -(y * __logf(pc + eps) + (1.f - y) * __logf(1.f - pc + eps));
+      const float inside = (p >= eps && p <= 1.f - eps) ? 1.f : 0.f;
+      float dz = -(y * __builtin_amdgcn_rcpf(pc + eps) - (1.f - y) * __builtin_amdgcn_rcpf(1.f - pc + eps)) * inside * p *
+                 (1.f - p) * inv_B;
+      if (!valid) { dz = 0.f; le = 0.f; }
+      // way back: dpre2 (all 8 in every lane), then this lane's two units of dpre1
+      float dha = 0.f, dhb = 0.f;
+      const float kav[8] = {ka0.x, ka0.y, ka0.z, ka0.w, ka1.x, ka1.y, ka1.z, ka1.w};
+      const float kbv[8] = {kb0.x, kb0.y, kb0.z, kb0.w, kb1.x, kb1.y, kb1.z, kb1.w};
+      float dp2[U2];
 #pragma unroll
-      for (int s2 = 0; s2 < 16; ++s2) bv[s2] = bp[2 * s2];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) xv[r] = xp[((r & 3) + 8 * (r >> 2)) * XS];     // all loads before the first MFMA
-#pragma unroll
-      for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc, 0, 0, 0);
-      float* vp = a.vals + ((ex0 + 4 * hi) * F + 2 * t) * E16 + lo;
-      if (n_ex == EX && 2 * t + 1 < F) {                     // whole tile inside the batch and the fields: no guards
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          vp[(int64_t)((r & 3) + 8 * (r >> 2)) * F * E16] = dzr[r] * (sr[r] - xv[r]) + acc[r];
-      } else if (2 * t + (lo >> 4) < F) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int e = (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (e < n_ex) vp[(int64_t)((r & 3) + 8 * (r >> 2)) * F * E16] = dzr[r] * (sr[r] - xv[r]) + acc[r];
+      for (int u = 0; u < U2; ++u) {
+        dp2[u] = h2[u] > 0.f ? dz * K2s[u] : 0.f;
+        dha += dp2[u] * kav[u];
+        dhb += dp2[u] * kbv[u];
+      }
+      DP1[e16 * HS1 + 2 * g16] = h1a > 0.f ? dha : 0.f;
+      DP1[e16 * HS1 + 2 * g16 + 1] = h1b > 0.f ? dhb : 0.f;
+      if (g16 == 0) {                                        // every lane of the group holds the same values
+        *reinterpret_cast<float4*>(h2s + e16 * U2) = make_float4(h2[0], h2[1], h2[2], h2[3]);
+        *reinterpret_cast<float4*>(h2s + e16 * U2 + 4) = make_float4(h2[4], h2[5], h2[6], h2[7]);
+        *reinterpret_cast<float4*>(dp2s + e16 * U2) = make_float4(dp2[0], dp2[1], dp2[2], dp2[3]);
+        *reinterpret_cast<float4*>(dp2s + e16 * U2 + 4) = make_float4(dp2[4], dp2[5], dp2[6], dp2[7]);
+        dzs[e16] = dz;
+        lss[e16] = le;
+        if (valid) {
+          a.gz[ex0 + e16] = dz;
+          if (a.prob) a.prob[ex0 + e16] = p;
         }
       }
     }
   }
+  __syncthreads();
+  STAMP(5);
 
-  if (a.stop == 6) return;
-
-  // ---- P6: per-workgroup dK0 = X^T . dpre1 on the matrix cores.  M = 16F rows of K0 in tiles of 32, wave w takes tiles
-  // w, w+4, ...; K = the 32 examples = 16 steps; B (dpre1) stays in registers.  P5 and P6 only read LDS: no barrier.
+  // ================================================ phase C ======================================================
   {
+    const int j = cj, q = cq;
+    // Both products are computed TRANSPOSED, so that an accumulator holds 4 consecutive floats of an output row
+    // (one 16-byte store per lane and tile instead of four 4-byte ones):
+    //   dX_f^T  [dim x example]  = K0_f [dim x unit] . dpre1^T [unit x example]     (M tile m = examples 16m..16m+15)
+    //   dK0_f^T [unit x dim]     = dpre1^T [unit x example] . X_f [example x dim]   (M tile n = units 16n..16n+15)
+    // operands made of dpre1, the same for every field (k slot q of step s <-> unit 8q+s resp. example ex(q,s)):
+    //   aP[m][s]  dpre1[example 16m + j][unit 8q + s]                      B of dX^T
+    //   bP[n][s]  dpre1[example ex(q,s)][unit 16n + j],  ex(q,s) = 4q + (s&3) + 16(s>>2)     A of dK0^T
+    float aP[2][8], bP[2][8], dzr[2];
+    float4 sr[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const float4 p0 = *reinterpret_cast<const float4*>(DP1 + (16 * m + j) * HS1 + 8 * q);
+      const float4 p1 = *reinterpret_cast<const float4*>(DP1 + (16 * m + j) * HS1 + 8 * q + 4);
+      aP[m][0] = p0.x; aP[m][1] = p0.y; aP[m][2] = p0.z; aP[m][3] = p0.w;
+      aP[m][4] = p1.x; aP[m][5] = p1.y; aP[m][6] = p1.z; aP[m][7] = p1.w;
+      dzr[m] = dzs[16 * m + j];
+      sr[m] = *reinterpret_cast<const float4*>(Ss + (16 * m + j) * E16 + 4 * q);
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) bP[n][s] = DP1[(4 * q + (s & 3) + 16 * (s >> 2)) * HS1 + 16 * n + j];
+
     float* part = a.dK0part + (int64_t)blockIdx.x * D * U1;
-    float bv[16];
+    // K0_f fragments (A of dX^T): K0[f*16 + j][8q .. 8q+8), two 16-byte loads per lane out of L2 (the first field's were
+    // requested before phase B); the next field's are in flight while this field is multiplied
 #pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2) bv[s2] = DP1[(2 * s2 + hi) * HS + lo];
-    for (int t = wave; t < n_tiles; t += 4) {
-      // A[i = row lo of the tile][k = example 2s+hi].  For an odd F the upper half of the last tile does not exist:
-      // those lanes read the start of the next LDS row instead, which only reaches D rows that are never stored
-      const float* ap = XT + hi * XS + t * 32 + lo;
-      f32x16 acc;
+    for (int i = 0; i < MAXFW; ++i) {
+      const int f = wave + NWV * i;
+      if (f >= F) break;                                              // wave-uniform
+      const float kt[8] = {kt0.x, kt0.y, kt0.z, kt0.w, kt1.x, kt1.y, kt1.z, kt1.w};
+      {
+        const int fn = f + NWV;
+        const float* kp = a.K0 + ((fn < F ? fn : f) * E16 + j) * U1 + 8 * q;
+        kt0 = *reinterpret_cast<const float4*>(kp);
+        kt1 = *reinterpret_cast<const float4*>(kp + 4);
+      }
+      // rows of this field: xk[s] = X[example ex(q,s)][f*16 + j]  (B of dK0^T; rows 4 apart are 16 banks apart) ...
+      float xk[8];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      float xv[16];
+      for (int s = 0; s < 8; ++s) xk[s] = XT[(4 * q + (s & 3) + 16 * (s >> 2)) * XS + f * E16 + j];
+      // ... and in the layout of dX^T's accumulator: xo[m] = X[example 16m + j][f*16 + 4q .. 4q+4)
+      float4 xo[2];
 #pragma unroll
-      for (int s2 = 0; s2 < 16; ++s2) xv[s2] = ap[2 * s2 * XS];
+      for (int m = 0; m < 2; ++m) xo[m] = *reinterpret_cast<const float4*>(XT + (16 * m + j) * XS + f * E16 + 4 * q);
+      f32x4 dx[2], dk[2];
 #pragma unroll
-      for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[s2], bv[s2], acc, 0, 0, 0);
-      float* pp = part + (t * 32 + 4 * hi) * U1 + lo;
-      if (t * 32 + 32 <= D) {
+      for (int m = 0; m < 2; ++m) {
+        dx[m][0] = 0.f; dx[m][1] = 0.f; dx[m][2] = 0.f; dx[m][3] = 0.f;
+        dk[m][0] = 0.f; dk[m][1] = 0.f; dk[m][2] = 0.f; dk[m][3] = 0.f;
+      }
+      // four independent accumulators, interleaved: the 16x16x4 product has a 40-cycle dependent latency
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pp[((r & 3) + 8 * (r >> 2)) * U1] = acc[r];
-      } else {
+      for (int s = 0; s < 8; ++s) {
+        dx[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(kt[s], aP[0][s], dx[0], 0, 0, 0);
+        dx[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kt[s], aP[1][s], dx[1], 0, 0, 0);
+        dk[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bP[0][s], xk[s], dk[0], 0, 0, 0);
+        dk[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bP[1][s], xk[s], dk[1], 0, 0, 0);
+      }
+      // IndexedSlices values: lane (example j of the tile, dims 4q..4q+3): 4 lanes cover the 64-byte (example, field) row
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi < D) pp[((r & 3) + 8 * (r >> 2)) * U1] = acc[r];
+      for (int m = 0; m < 2; ++m) {
+        const int e = 16 * m + j;
+        if (e < n_ex) {
+          float4 o;
+          o.x = dzr[m] * (sr[m].x - xo[m].x) + dx[m][0];
+          o.y = dzr[m] * (sr[m].y - xo[m].y) + dx[m][1];
+          o.z = dzr[m] * (sr[m].z - xo[m].z) + dx[m][2];
+          o.w = dzr[m] * (sr[m].w - xo[m].w) + dx[m][3];
+          if (DIRECT && dl[i][m] >= 0) {
+            // head of its run: the row is final unless the run has more members (the post launch adds those)
+            *reinterpret_cast<float4*>(a.g_embed + (int64_t)dl[i][m] * E16 + 4 * q) = o;
+          } else
+            *reinterpret_cast<float4*>(a.vals + ((ex0 + e) * F + f) * E16 + 4 * q) = o;
+        }
+      }
+      // dK0 partial: row f*16 + j (this lane's dim), units 16n + 4q .. +4
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        *reinterpret_cast<float4*>(part + (f * E16 + j) * U1 + 16 * n + 4 * q) =
+            make_float4(dk[n][0], dk[n][1], dk[n][2], dk[n][3]);
+    }
+
+    STAMP(6);                                   // this wave's fields are done
+    // small per-workgroup partials (fixed order over the 32 examples), spread over the waves that own fewer fields
+    float* sm = a.small + (int64_t)blockIdx.x * SMALL;
+    if (wave >= 4) {
+      const int t2 = tid - 256, k = t2 >> 3, u = t2 & 7;
+      float s = 0.f;
+#pragma unroll 8
+      for (int e = 0; e < EX; ++e) s += H1s[e * HS1 + k] * dp2s[e * U2 + u];
+      sm[t2] = s;                                              // dK1 [32][8]
+    } else if (wave == 3) {
+      if (lane < U1) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int e = 0; e < EX; ++e) t += DP1[e * HS1 + lane];
+        sm[256 + lane] = t;                                    // db0
+      }
+    } else if (wave == 2) {
+      if (lane < U2) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll 8
+        for (int e = 0; e < EX; ++e) { t1 += dp2s[e * U2 + lane]; t2 += h2s[e * U2 + lane] * dzs[e]; }
+        sm[288 + lane] = t1;                                   // db1
+        sm[296 + lane] = t2;                                   // dK2
+      } else if (lane == 32) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll 8
+        for (int e = 0; e < EX; ++e) { t1 += dzs[e]; t2 += lss[e]; }
+        sm[304] = t1;                                          // db2 = dbias
+        sm[305] = t2;                                          // sum of per-example BCE terms
       }
     }
   }
+  STAMP(7);
 }
 
 // fixed-order sum of the per-workgroup partials.  1024 threads = 16 slices x 64 lanes; lane owns 4 consecutive
@@ -405,6 +526,16 @@ struct ReduceArgs {
   float* dK0; float* dK1; float* db0; float* db1; float* dK2; float* db2; float* dbias; float* loss;
 };
 
+// 1024 threads = 64 slices x 16 lanes; a lane owns 4 consecutive outputs (float4), slice q adds the partials of
+// workgroups q, q+64, q+128, ... (all of them in flight before the first add), then the 64 slices meet in LDS and are
+// added in a fixed two-level order.  16 float4 columns per workgroup -> 208 + 5 workgroups at F = 26: with 64 columns
+// per workgroup (round 1) only 54 CUs shared the 13.6 MB of partials, 256 KB each, and the reduction took ~10 us.
+constexpr int RC = 16;         // float4 columns per reduce workgroup
+constexpr int RS = 64;         // slices
+__host__ __device__ inline int reduce_blocks(int D) {
+  return (int)(((int64_t)D * U1 / 4 + RC - 1) / RC) + (SMALL / 4 + RC - 1) / RC;
+}
+
 __device__ __forceinline__ void reduce_body(const ReduceArgs& r, int bidx) {
   const float* __restrict__ dK0part = r.dK0part;
   const float* __restrict__ small = r.small;
@@ -413,41 +544,66 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs& r, int bidx) {
   float* __restrict__ dK0 = r.dK0; float* __restrict__ dK1 = r.dK1; float* __restrict__ db0 = r.db0;
   float* __restrict__ db1 = r.db1; float* __restrict__ dK2 = r.dK2; float* __restrict__ db2 = r.db2;
   float* __restrict__ dbias = r.dbias; float* __restrict__ loss = r.loss;
-  __shared__ float4 red[16][64];
-  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  __shared__ float4 red[RS][RC];
+  __shared__ float4 red2[8][RC];
+  const int lane = threadIdx.x & (RC - 1), q = threadIdx.x / RC;
   const int64_t n0 = (int64_t)D * U1;                  // multiple of 4
-  const int nb0 = (int)((n0 / 4 + 63) / 64);           // blocks that cover dK0
+  const int nb0 = (int)((n0 / 4 + RC - 1) / RC);       // blocks that cover dK0
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   int64_t e4 = 0;
-  bool is_small = bidx >= nb0;
+  const bool is_small = bidx >= nb0;
+  const float* src;
+  int64_t stride;
+  bool in = false;
   if (!is_small) {
-    e4 = (int64_t)bidx * 64 + lane;                    // float4 index into dK0
-    if (e4 * 4 < n0)
-      for (int w = q; w < nwg; w += 16) {
-        float4 x = *reinterpret_cast<const float4*>(dK0part + (int64_t)w * n0 + e4 * 4);
-        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
-      }
+    e4 = (int64_t)bidx * RC + lane;                    // float4 index into dK0
+    in = e4 * 4 < n0;
+    src = dK0part + e4 * 4;
+    stride = n0;
   } else {
-    e4 = (int64_t)(bidx - nb0) * 64 + lane;             // float4 index into the SMALL block
-    if (e4 * 4 < SMALL)
-      for (int w = q; w < nwg; w += 16) {
-        float4 x = *reinterpret_cast<const float4*>(small + (int64_t)w * SMALL + e4 * 4);
-        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
-      }
+    e4 = (int64_t)(bidx - nb0) * RC + lane;            // float4 index into the SMALL block
+    in = e4 * 4 < SMALL;
+    src = small + e4 * 4;
+    stride = SMALL;
+  }
+  if (in) {
+    int w = q;
+    for (; w + 3 * RS < nwg; w += 4 * RS) {
+      float4 x[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = *reinterpret_cast<const float4*>(src + (int64_t)(w + RS * j) * stride);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc.x += x[j].x; acc.y += x[j].y; acc.z += x[j].z; acc.w += x[j].w; }
+    }
+    for (; w < nwg; w += RS) {
+      float4 x = *reinterpret_cast<const float4*>(src + (int64_t)w * stride);
+      acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+    }
   }
   red[q][lane] = acc;
   __syncthreads();
-  if (q != 0) return;
-  float4 s = red[0][lane];
+  if (q < 8) {                                         // slices 8q .. 8q+7, in order
+    float4 s = red[8 * q][lane];
 #pragma unroll
-  for (int k = 1; k < 16; ++k) {
-    float4 x = red[k][lane];
+    for (int k = 1; k < 8; ++k) {
+      float4 x = red[8 * q + k][lane];
+      s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+    }
+    red2[q][lane] = s;
+  }
+  __syncthreads();
+  if (q != 0) return;
+  float4 s = red2[0][lane];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) {
+    float4 x = red2[k][lane];
     s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
   }
   if (!is_small) {
     if (e4 * 4 < n0) *reinterpret_cast<float4*>(dK0 + e4 * 4) = s;
     return;
   }
+  if (e4 * 4 >= SMALL) return;
   float sv[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -463,12 +619,7 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs& r, int bidx) {
 
 __global__ __launch_bounds__(1024) void deepfm_reduce_kernel(ReduceArgs r) { reduce_body(r, (int)blockIdx.x); }
 
-size_t fused_lds_bytes(int F) {
-  size_t D = (size_t)F * E16;
-  size_t f = (size_t)EX * (D + 2) + D * HS + 2 * (size_t)EX * HS + (size_t)EX * E16 + 2 * (size_t)EX * U2 +
-             3 * (size_t)EX + U1 * U2 + U1 + 2 * U2 + 4 * (size_t)EX * HS;
-  return f * sizeof(float);
-}
+size_t fused_lds_bytes(int F) { return (size_t)carve_of(F).total * sizeof(float); }
 
 // ------------------------------------------------------------------------------------------------
 // per-column sort of the de-duplication plan, three short kernels so that ~200 CUs work on it instead of F:
@@ -490,6 +641,7 @@ struct ColSortArgs {
   int32_t* col_seg;     // [F][B+1] run starts in the column's sorted order (tail = B)
   int32_t* col_nu;      // [F]
   int* bad;
+  int32_t* dloc;        // [F][B] or null: run index of lookup (f, example) inside its column, sign bit = not the run's head
 };
 
 __global__ __launch_bounds__(256) void colsort_chunk_kernel(Cols cols, const int64_t* __restrict__ col_lo, ColSortArgs a) {
@@ -663,6 +815,8 @@ __global__ __launch_bounds__(256) void colsort_heads_kernel(const int64_t* __res
       a.col_seg[(int64_t)f * (B + 1) + rank] = (int32_t)s;
       ++rank;
     }
+    // position 0 is always a head, so rank >= 1 here: the run this position belongs to is rank - 1
+    if (a.dloc && s < B) a.dloc[(int64_t)f * B + (v[r] & pmask)] = hd[r] ? rank - 1 : (int32_t)((uint32_t)(rank - 1) | 0x80000000u);
     if (s < B && s + 1 >= all) a.col_seg[(int64_t)f * (B + 1) + s + 1] = (int32_t)B;   // tail [all .. B] = B
   }
   if (q == 0 && tid == 0) a.col_nu[f] = all;
@@ -787,6 +941,114 @@ __device__ __forceinline__ void colseg_body(const ColSegArgs& k, int bidx) {
 
 __global__ __launch_bounds__(256) void colseg_sum_kernel(ColSegArgs k) { colseg_body(k, (int)blockIdx.x); }
 
+// ---- direct mode: what is left for the launch after the fused kernel.  ONE LANE per run (slot) of the plan:
+//   a run of one lookup (almost all of them with uniform ids): g_w = gz of that lookup, uniq_ids = its id -- coalesced
+//     stores, the value row is already in place;
+//   a run of 2..8 lookups: the lane adds the other members' value rows to the head's row itself (position order);
+//   a longer run: the whole wave adds it, 16 members x 4 float4 chunks per round, fixed butterfly over the 16 rows;
+//   slots beyond the column's runs: the zero-padded tail.
+// A wave takes 4 consecutive runs from each sixteenth of a column (when B is a multiple of 64), so that neighbouring
+// hot ids -- the synthetic Zipf draws make the smallest ids of a field the frequent ones -- fall to different waves.
+constexpr int FIX_T = 1024;
+__device__ __forceinline__ void fixup_body(const ColSegArgs& k, int bidx) {
+  const float4* __restrict__ vals = k.vals;
+  const float* __restrict__ gz = k.gz;
+  const int64_t B = k.B;
+  const int F = k.F;
+  float4* __restrict__ g_embed = k.g_embed;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int per_col = (int)((B + FIX_T - 1) / FIX_T);           // workgroups per column
+  const int f = bidx / per_col;
+  const int t = (bidx - f * per_col) * FIX_T + tid;             // slot of the column before the deal
+  int u = t;
+  if ((B & 63) == 0) {
+    const int w = t >> 6, l = t & 63;
+    u = (l >> 2) * (int)(B >> 4) + 4 * w + (l & 3);
+  }
+  __shared__ int nu_s[REC_MAX_COLS];
+  if (tid < F) nu_s[tid] = k.col_nu[tid];
+  __syncthreads();
+  int64_t before = 0, total = 0;
+  for (int q = 0; q < F; ++q) {
+    const int nq = nu_s[q];
+    if (q < f) before += nq;
+    total += nq;
+  }
+  const int nu = nu_s[f];
+  const bool in_col = t < B;
+  const bool live = in_col && u < nu;
+  const int32_t* pf = k.perm + (int64_t)f * B;
+  int s0 = 0, s1 = 0;
+  if (live) {
+    s0 = k.col_seg[(int64_t)f * (B + 1) + u];
+    s1 = k.col_seg[(int64_t)f * (B + 1) + u + 1];
+  }
+  const int len = s1 - s0;
+  const int64_t dst = before + u;
+  if (live) {
+    float accw = gz[pf[s0]];
+    if (len > 1 && len <= 8) {                                  // short run: this lane alone
+      float4 a0 = g_embed[dst * 4], a1 = g_embed[dst * 4 + 1], a2 = g_embed[dst * 4 + 2], a3 = g_embed[dst * 4 + 3];
+      for (int s = s0 + 1; s < s1; ++s) {
+        const int64_t b = pf[s];
+        const float4* r = vals + (b * F + f) * 4;
+        const float4 x0 = r[0], x1 = r[1], x2 = r[2], x3 = r[3];
+        a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
+        a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
+        a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w;
+        a3.x += x3.x; a3.y += x3.y; a3.z += x3.z; a3.w += x3.w;
+        accw += gz[b];
+      }
+      g_embed[dst * 4] = a0; g_embed[dst * 4 + 1] = a1; g_embed[dst * 4 + 2] = a2; g_embed[dst * 4 + 3] = a3;
+    }
+    if (len <= 8) k.g_w[dst] = accw;
+    k.uniq_ids[dst] = k.col_uid[(int64_t)f * B + u];
+  } else if (in_col) {
+    // padded tail: slot = total + rank among the column's unused slots; id = the smallest id of column 0, zero rows
+    const int64_t d2 = total + ((int64_t)f * B - before) + (u - nu);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    g_embed[d2 * 4] = z; g_embed[d2 * 4 + 1] = z; g_embed[d2 * 4 + 2] = z; g_embed[d2 * 4 + 3] = z;
+    k.g_w[d2] = 0.f;
+    k.uniq_ids[d2] = k.col_uid[0];
+  }
+  // long runs, one at a time, by the whole wave: lane = (member slot r of 16, chunk c of 4)
+  unsigned long long longm = __ballot(live && len > 8);
+  const int r = lane >> 2, c = lane & 3;
+  while (longm) {
+    const int src = __ffsll((long long)longm) - 1;
+    longm &= longm - 1;
+    const int rs0 = __shfl(s0, src, 64), rs1 = __shfl(s1, src, 64);
+    const int64_t rdst = before + __shfl(u, src, 64);
+    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f);
+    float pw = 0.f;
+#pragma unroll 4
+    for (int s = rs0 + 1 + r; s < rs1; s += 16) {              // independent loads: several rounds in flight
+      const int64_t b = pf[s];
+      const float4 x = vals[(b * F + f) * 4 + c];
+      pa.x += x.x; pa.y += x.y; pa.z += x.z; pa.w += x.w;
+      pw += gz[b];
+    }
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) {                         // fixed butterfly over the 16 member slots
+      pa.x += __shfl_xor(pa.x, o, 64); pa.y += __shfl_xor(pa.y, o, 64);
+      pa.z += __shfl_xor(pa.z, o, 64); pa.w += __shfl_xor(pa.w, o, 64);
+      pw += __shfl_xor(pw, o, 64);
+    }
+    if (r == 0) {
+      float4 h = g_embed[rdst * 4 + c];
+      h.x += pa.x; h.y += pa.y; h.z += pa.z; h.w += pa.w;
+      g_embed[rdst * 4 + c] = h;
+      if (c == 0) k.g_w[rdst] = gz[pf[rs0]] + pw;
+    }
+  }
+  if (bidx == 0 && tid == 0) *k.n_uniq = total;
+}
+
+__global__ __launch_bounds__(1024) void deepfm_post_direct_kernel(ReduceArgs r, ColSegArgs k, int nb_reduce) {
+  if ((int)blockIdx.x < nb_reduce) reduce_body(r, (int)blockIdx.x);
+  else fixup_body(k, (int)blockIdx.x - nb_reduce);
+}
+
 // reduction of the workgroup partials and the segment sums only depend on the fused kernel, not on each other: one
 // launch, the first nb_reduce workgroups (1024 threads) reduce, the others sum segments -- they run side by side
 __global__ __launch_bounds__(1024) void deepfm_post_kernel(ReduceArgs r, ColSegArgs k, int nb_reduce) {
@@ -802,12 +1064,25 @@ extern "C" size_t rec_deepfm_fused_workspace_bytes(int64_t B, int F) {
   return sizeof(float) * nwg * ((size_t)F * E16 * U1 + SMALL) + 256;
 }
 
+#ifdef REC_FUSED_STAMPS
+// diagnostic build only (scripts/exp/fused_stamps.py builds it into its own library): phase stamps of the last launch
+static unsigned long long* g_fused_stamps = nullptr;
+extern "C" int rec_debug_fused_stamps(unsigned long long* host_out, int nwg) {
+  if (!g_fused_stamps) return REC_E_ARG;
+  return (int)hipMemcpy(host_out, g_fused_stamps, sizeof(unsigned long long) * 12 * NWV * (size_t)nwg, hipMemcpyDeviceToHost);
+}
+#endif
+
+struct DirectArgs {
+  const int32_t* dloc; const int32_t* col_nu; float* g_embed; float* g_w; int64_t* uniq_ids;
+};
+
 static int launch_fused(const float* table, int64_t ld, int64_t V, const int64_t* const* cols_host, int F, int64_t B,
                         const float* bias, const float* K0, const float* b0, const float* K1, const float* b1,
                         const float* K2, const float* b2, const float* label, float* gz, float* vals, float* prob,
                         float* dK0, float* db0, float* dK1, float* db1, float* dK2, float* db2, float* dbias,
                         float* loss, int* oob_flag, void* workspace, void* stream, const ColSegArgs* seg,
-                        bool main_only = false) {
+                        bool main_only = false, const DirectArgs* direct = nullptr) {
   if (B <= 0 || F <= 0 || V <= 0) return REC_E_ARG;
   if (ld != LD || F > 28 || F > REC_MAX_COLS || V >= (int64_t(1) << 31)) return REC_E_UNSUPPORTED;
   if (!table || !cols_host || !bias || !K0 || !b0 || !K1 || !b1 || !K2 || !b2 || !label || !gz || !vals || !dK0 ||
@@ -825,20 +1100,33 @@ static int launch_fused(const float* table, int64_t ld, int64_t V, const int64_t
   int nwg = (int)ceil_div64(B, EX);
   float* dK0part = (float*)workspace;
   float* small = dK0part + (size_t)nwg * F * E16 * U1;
-#ifdef REC_DEBUG_PHASE_STOPS   // profiling builds only (scripts/exp/*_phases.sh): the kernel stops after phase N
-  static const int stop = getenv("REC_FUSED_STOP") ? atoi(getenv("REC_FUSED_STOP")) : 0;
+#ifdef REC_FUSED_STAMPS
+  static unsigned long long* stamps = nullptr;
+  if (!stamps && hipMalloc(&stamps, sizeof(unsigned long long) * 12 * NWV * 65536) != hipSuccess) return REC_E_ARG;
+  g_fused_stamps = stamps;
+  FusedArgs a{table, V, bias, K0, b0, K1, b1, K2, b2, label, B, F, gz, vals, prob, dK0part, small, oob_flag,
+              direct ? direct->dloc : nullptr, direct ? direct->col_nu : nullptr, direct ? direct->g_embed : nullptr,
+              direct ? direct->g_w : nullptr, direct ? direct->uniq_ids : nullptr, stamps};
 #else
-  constexpr int stop = 0;
+  FusedArgs a{table, V, bias, K0, b0, K1, b1, K2, b2, label, B, F, gz, vals, prob, dK0part, small, oob_flag,
+              direct ? direct->dloc : nullptr, direct ? direct->col_nu : nullptr, direct ? direct->g_embed : nullptr,
+              direct ? direct->g_w : nullptr, direct ? direct->uniq_ids : nullptr};
 #endif
-  FusedArgs a{table, V, bias, K0, b0, K1, b1, K2, b2, label, B, F, gz, vals, prob, dK0part, small, oob_flag, stop};
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(deepfm_fwd_bwd_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(deepfm_fwd_bwd_kernel, dim3(nwg), dim3(256), lds, st, cp, a);
+  if (direct) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(deepfm_fwd_bwd_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(deepfm_fwd_bwd_kernel<true>, dim3(nwg), dim3(512), lds, st, cp, a);
+  } else {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(deepfm_fwd_bwd_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(deepfm_fwd_bwd_kernel<false>, dim3(nwg), dim3(512), lds, st, cp, a);
+  }
   REC_LAUNCH_CHECK();
   if (main_only) return REC_OK;
   int D = F * E16;
-  unsigned nb = (unsigned)ceil_div64((int64_t)D * U1 / 4, 64) + (unsigned)ceil_div64(SMALL / 4, 64);
+  unsigned nb = (unsigned)reduce_blocks(D);
   ReduceArgs r{dK0part, small, nwg, D, B, dK0, dK1, db0, db1, dK2, db2, dbias, loss};
   if (seg) {
     unsigned nbs = (unsigned)ceil_div64(B * F * 4, 1024);
@@ -892,30 +1180,73 @@ extern "C" int rec_deepfm_fused_main_f32(const float* table, int64_t ld, int64_t
                       d, d, d, oob_flag, workspace, stream, nullptr, true);
 }
 
-extern "C" int rec_deepfm_fused_post_f32(int F, int64_t B, const float* gz, const float* vals, float* dK0, float* db0,
-                                         float* dK1, float* db1, float* dK2, float* db2, float* dbias, float* loss,
-                                         void* workspace, const int32_t* perm, const int64_t* col_uid,
-                                         const int32_t* col_seg, const int32_t* col_nu, int64_t* uniq_ids,
-                                         float* g_embed_rows, float* g_w_rows, int64_t* n_uniq, int packed,
-                                         void* stream) {
+static int launch_post(bool direct, int F, int64_t B, const float* gz, const float* vals, float* dK0, float* db0,
+                       float* dK1, float* db1, float* dK2, float* db2, float* dbias, float* loss, void* workspace,
+                       const int32_t* perm, const int64_t* col_uid, const int32_t* col_seg, const int32_t* col_nu,
+                       int64_t* uniq_ids, float* g_embed_rows, float* g_w_rows, int64_t* n_uniq, int packed,
+                       void* stream) {
   if (B <= 0 || F <= 0 || F > 28) return REC_E_ARG;
   if (!gz || !vals || !dK0 || !db0 || !dK1 || !db1 || !dK2 || !db2 || !dbias || !loss || !workspace || !perm ||
       !col_uid || !col_seg || !col_nu || !uniq_ids || !g_embed_rows || !n_uniq || (!packed && !g_w_rows))
     return REC_E_ARG;
+  if (direct && packed) return REC_E_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(vals) & 15) != 0 || (reinterpret_cast<uintptr_t>(g_embed_rows) & 15) != 0)
     return REC_E_UNSUPPORTED;
   int nwg = (int)ceil_div64(B, EX);
   int D = F * E16;
   float* dK0part = (float*)workspace;
   float* small = dK0part + (size_t)nwg * F * E16 * U1;
-  unsigned nb = (unsigned)ceil_div64((int64_t)D * U1 / 4, 64) + (unsigned)ceil_div64(SMALL / 4, 64);
+  unsigned nb = (unsigned)reduce_blocks(D);
   unsigned nbs = (unsigned)ceil_div64(B * F * 4, 1024);
   ReduceArgs r{dK0part, small, nwg, D, B, dK0, dK1, db0, db1, dK2, db2, dbias, loss};
   ColSegArgs k{(const float4*)vals, gz, perm, col_uid, col_seg, col_nu, B, F, uniq_ids, (float4*)g_embed_rows,
                packed ? (float*)nullptr : g_w_rows, n_uniq, packed ? 1 : 0};
-  hipLaunchKernelGGL(deepfm_post_kernel, dim3(nb + nbs), dim3(1024), 0, as_stream(stream), r, k, (int)nb);
+  if (direct) {
+    unsigned nbf = (unsigned)F * (unsigned)ceil_div64(B, FIX_T);
+    hipLaunchKernelGGL(deepfm_post_direct_kernel, dim3(nb + nbf), dim3(1024), 0, as_stream(stream), r, k, (int)nb);
+  } else {
+    hipLaunchKernelGGL(deepfm_post_kernel, dim3(nb + nbs), dim3(1024), 0, as_stream(stream), r, k, (int)nb);
+  }
   REC_LAUNCH_CHECK();
   return REC_OK;
+}
+
+extern "C" int rec_deepfm_fused_post_f32(int F, int64_t B, const float* gz, const float* vals, float* dK0, float* db0,
+                                         float* dK1, float* db1, float* dK2, float* db2, float* dbias, float* loss,
+                                         void* workspace, const int32_t* perm, const int64_t* col_uid,
+                                         const int32_t* col_seg, const int32_t* col_nu, int64_t* uniq_ids,
+                                         float* g_embed_rows, float* g_w_rows, int64_t* n_uniq, int packed,
+                                         void* stream) {
+  return launch_post(false, F, B, gz, vals, dK0, db0, dK1, db1, dK2, db2, dbias, loss, workspace, perm, col_uid, col_seg,
+                     col_nu, uniq_ids, g_embed_rows, g_w_rows, n_uniq, packed, stream);
+}
+
+// direct mode: the plan (rec_colsort_plan_dest_i64) exists BEFORE the fused kernel runs; the kernel writes the value row
+// of every run's first member straight into g_embed_rows, rec_deepfm_fused_post_direct_f32 finishes runs with more
+// members, fills uniq_ids / g_w_rows / n_uniq and the padded tail, and reduces the dense partials
+extern "C" int rec_deepfm_fused_main_direct_f32(const float* table, int64_t ld, int64_t V,
+                                                const int64_t* const* cols_host, int F, int64_t B, const float* bias,
+                                                const float* K0, const float* b0, const float* K1, const float* b1,
+                                                const float* K2, const float* b2, const float* label, float* gz,
+                                                float* vals, float* prob, int* oob_flag, void* workspace,
+                                                const int32_t* dloc, const int32_t* col_nu, float* g_embed_rows,
+                                                void* stream) {
+  if (!dloc || !col_nu || !g_embed_rows) return REC_E_ARG;
+  if ((reinterpret_cast<uintptr_t>(g_embed_rows) & 15) != 0) return REC_E_UNSUPPORTED;
+  float dummy = 0.f;
+  float* d = &dummy;
+  DirectArgs da{dloc, col_nu, g_embed_rows, nullptr, nullptr};
+  return launch_fused(table, ld, V, cols_host, F, B, bias, K0, b0, K1, b1, K2, b2, label, gz, vals, prob, d, d, d, d, d,
+                      d, d, d, oob_flag, workspace, stream, nullptr, true, &da);
+}
+
+extern "C" int rec_deepfm_fused_post_direct_f32(int F, int64_t B, const float* gz, const float* vals, float* dK0,
+                                                float* db0, float* dK1, float* db1, float* dK2, float* db2, float* dbias,
+                                                float* loss, void* workspace, const int32_t* perm, const int64_t* col_uid,
+                                                const int32_t* col_seg, const int32_t* col_nu, int64_t* uniq_ids,
+                                                float* g_embed_rows, float* g_w_rows, int64_t* n_uniq, void* stream) {
+  return launch_post(true, F, B, gz, vals, dK0, db0, dK1, db1, dK2, db2, dbias, loss, workspace, perm, col_uid, col_seg,
+                     col_nu, uniq_ids, g_embed_rows, g_w_rows, n_uniq, 0, stream);
 }
 
 extern "C" size_t rec_colsort_workspace_bytes(int64_t B, int F) {
@@ -925,9 +1256,9 @@ extern "C" size_t rec_colsort_workspace_bytes(int64_t B, int F) {
   return sizeof(uint32_t) * (size_t)F * ((size_t)np + (size_t)B) + 256;
 }
 
-extern "C" int rec_colsort_plan_i64(const int64_t* const* cols_host, int F, int64_t B, int64_t V, const int64_t* col_lo,
-                                    int64_t max_key, int32_t* perm, int64_t* col_uid, int32_t* col_seg, int32_t* col_nu,
-                                    int* bad_flag, void* workspace, void* stream) {
+static int colsort_plan(const int64_t* const* cols_host, int F, int64_t B, int64_t V, const int64_t* col_lo,
+                        int64_t max_key, int32_t* perm, int64_t* col_uid, int32_t* col_seg, int32_t* col_nu,
+                        int32_t* dloc, int* bad_flag, void* workspace, void* stream) {
   if (!cols_host || !col_lo || !perm || !col_uid || !col_seg || !col_nu || !workspace || F <= 0 || B <= 0 || V <= 0 ||
       max_key < 0)
     return REC_E_ARG;
@@ -948,7 +1279,7 @@ extern "C" int rec_colsort_plan_i64(const int64_t* const* cols_host, int F, int6
   int nch = (int)(np / CHK);
   uint32_t* chunks = (uint32_t*)workspace;
   uint32_t* sorted = chunks + (size_t)F * np;
-  ColSortArgs a{B, F, V, key_bits, pos_bits, nch, chunks, sorted, perm, col_uid, col_seg, col_nu, bad_flag};
+  ColSortArgs a{B, F, V, key_bits, pos_bits, nch, chunks, sorted, perm, col_uid, col_seg, col_nu, bad_flag, dloc};
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(colsort_chunk_kernel, dim3(nch, F), dim3(256), 0, st, cp, col_lo, a);
   REC_LAUNCH_CHECK();
@@ -957,6 +1288,22 @@ extern "C" int rec_colsort_plan_i64(const int64_t* const* cols_host, int F, int6
   hipLaunchKernelGGL(colsort_heads_kernel, dim3(nch, F), dim3(256), 0, st, col_lo, a);
   REC_LAUNCH_CHECK();
   return REC_OK;
+}
+
+extern "C" int rec_colsort_plan_i64(const int64_t* const* cols_host, int F, int64_t B, int64_t V, const int64_t* col_lo,
+                                    int64_t max_key, int32_t* perm, int64_t* col_uid, int32_t* col_seg, int32_t* col_nu,
+                                    int* bad_flag, void* workspace, void* stream) {
+  return colsort_plan(cols_host, F, B, V, col_lo, max_key, perm, col_uid, col_seg, col_nu, nullptr, bad_flag, workspace,
+                      stream);
+}
+
+extern "C" int rec_colsort_plan_dest_i64(const int64_t* const* cols_host, int F, int64_t B, int64_t V,
+                                         const int64_t* col_lo, int64_t max_key, int32_t* perm, int64_t* col_uid,
+                                         int32_t* col_seg, int32_t* col_nu, int32_t* dloc, int* bad_flag, void* workspace,
+                                         void* stream) {
+  if (!dloc) return REC_E_ARG;
+  return colsort_plan(cols_host, F, B, V, col_lo, max_key, perm, col_uid, col_seg, col_nu, dloc, bad_flag, workspace,
+                      stream);
 }
 
 extern "C" int rec_colseg_sum_f32(const float* vals, const float* gz, const int32_t* perm, const int64_t* col_uid,

@@ -275,8 +275,10 @@ class DeepFMFusedStep:
 
     NBUF = 16           # plan buffers (see __init__): two halves of 8, many() alternates between them
 
-    def __init__(self, layer, batch_size, field_dims, field_offsets, optimizer=None, lr=1e-3, use_graph=True):
+    def __init__(self, layer, batch_size, field_dims, field_offsets, optimizer=None, lr=1e-3, use_graph=True,
+                 direct=True):
         self.layer = layer
+        self.direct = bool(direct)
         self.B = B = int(batch_size)
         self.F = F = len(layer.feature_names)
         emb, w = layer.embed.embeddings, layer.w.embeddings
@@ -319,13 +321,14 @@ class DeepFMFusedStep:
         self._col_uid = torch.empty((NB, F, B), dtype=torch.int64, device=dev)
         self._col_seg = torch.empty((NB, F, B + 1), dtype=torch.int32, device=dev)
         self._col_nu = torch.zeros((NB, F), dtype=torch.int32, device=dev)
+        self._dloc = torch.empty((NB, F, B), dtype=torch.int32, device=dev)
         self.plans = [dict(perm=self._perm[b], col_uid=self._col_uid[b], col_seg=self._col_seg[b],
-                           col_nu=self._col_nu[b]) for b in range(NB)]
+                           col_nu=self._col_nu[b], dloc=self._dloc[b]) for b in range(NB)]
         # consecutive buffers are contiguous, so ONE sort call can build the plans of GROUP upcoming batches as
         # GROUP*F columns (the sort kernels are latency-bound at < 1 wave per SIMD: two batches cost ~1.2x one)
         self.GROUP = max(1, min(2, 64 // F))
         self.col_lo_rep = self.col_lo.repeat(self.GROUP).contiguous()
-        self._plan_key, self._plan_buf = None, 0
+        self._prefetched, self._half = {}, 0     # plans announced by the previous call: id-tensor addresses -> buffer
         self.uniq_ids = torch.empty(n, dtype=torch.int64, device=dev)
         self.g_embed_rows = torch.empty((n, 16), **f32)
         self.g_w_rows = torch.empty((n, 1), **f32)
@@ -349,56 +352,49 @@ class DeepFMFusedStep:
         assert 1 <= k <= self.GROUP and first_buf + k <= self.NBUF
         arr = (C.c_void_p * (k * F))(*[c.data_ptr() for cols in cols_list for c in cols])
         pl = self.plans[first_buf]
-        check(lib.rec_colsort_plan_i64(arr, k * F, self.B, self.V, _p(self.col_lo_rep), self.max_key, _p(pl["perm"]),
-                                       _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.bad_ids),
-                                       _p(self.sort_ws), C.c_void_p(stream.cuda_stream)), "rec_colsort_plan_i64")
+        check(lib.rec_colsort_plan_dest_i64(arr, k * F, self.B, self.V, _p(self.col_lo_rep), self.max_key,
+                                            _p(pl["perm"]), _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]),
+                                            _p(pl["dloc"]), _p(self.bad_ids), _p(self.sort_ws),
+                                            C.c_void_p(stream.cuda_stream)), "rec_colsort_plan_dest_i64")
 
-    def _launch_main(self, cols, label, st):
+    def _launch_main(self, cols, label, st, buf):
+        """The fused kernel.  Direct mode: the plan in buffer ``buf`` is complete, so the value row of every run's first
+        member goes straight to its slot of g_embed_rows (with gz and the id)."""
         L, F = self.layer, self.F
         arr = (C.c_void_p * F)(*[c.data_ptr() for c in cols])
         emb = L.embed.embeddings
-        check(lib.rec_deepfm_fused_main_f32(
+        pl = self.plans[buf]
+        if not self.direct:
+            check(lib.rec_deepfm_fused_main_f32(
+                _p(emb), emb.stride(0), self.V, arr, F, self.B, _p(L.bias), _p(L.MLP_layer1.kernel_0),
+                _p(L.MLP_layer1.bias_0), _p(L.MLP_layer1.kernel_1), _p(L.MLP_layer1.bias_1),
+                _p(L.MLP_layer2.kernel_0), _p(L.MLP_layer2.bias_0), _p(label), _p(self.gz), _p(self.vals), None,
+                _p(self.oob), _p(self.ws), st), "rec_deepfm_fused_main_f32")
+            return
+        check(lib.rec_deepfm_fused_main_direct_f32(
             _p(emb), emb.stride(0), self.V, arr, F, self.B, _p(L.bias), _p(L.MLP_layer1.kernel_0),
             _p(L.MLP_layer1.bias_0), _p(L.MLP_layer1.kernel_1), _p(L.MLP_layer1.bias_1), _p(L.MLP_layer2.kernel_0),
-            _p(L.MLP_layer2.bias_0), _p(label), _p(self.gz), _p(self.vals), None, _p(self.oob), _p(self.ws), st),
-            "rec_deepfm_fused_main_f32")
+            _p(L.MLP_layer2.bias_0), _p(label), _p(self.gz), _p(self.vals), None, _p(self.oob), _p(self.ws),
+            _p(pl["dloc"]), _p(pl["col_nu"]), _p(self.g_embed_rows), st), "rec_deepfm_fused_main_direct_f32")
 
     def _launch_post(self, buf, st):
-        """reduction of the workgroup partials and the segment sums side by side in ONE launch"""
+        """reduction of the workgroup partials side by side with the segment sums (direct mode: with what is left of
+        them -- runs of more than one lookup and the padded tail) in ONE launch"""
         g, pl = self.g, self.plans[buf]
-        check(lib.rec_deepfm_fused_post_f32(
+        if not self.direct:
+            check(lib.rec_deepfm_fused_post_f32(
+                self.F, self.B, _p(self.gz), _p(self.vals), _p(g["MLP_layer1.kernel_0"]), _p(g["MLP_layer1.bias_0"]),
+                _p(g["MLP_layer1.kernel_1"]), _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]),
+                _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(self.loss), _p(self.ws), _p(pl["perm"]),
+                _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.uniq_ids), _p(self.g_embed_rows),
+                _p(self.g_w_rows), _p(self.n_uniq), 0, st), "rec_deepfm_fused_post_f32")
+            return
+        check(lib.rec_deepfm_fused_post_direct_f32(
             self.F, self.B, _p(self.gz), _p(self.vals), _p(g["MLP_layer1.kernel_0"]), _p(g["MLP_layer1.bias_0"]),
             _p(g["MLP_layer1.kernel_1"]), _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]),
             _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(self.loss), _p(self.ws), _p(pl["perm"]), _p(pl["col_uid"]),
             _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.uniq_ids), _p(self.g_embed_rows), _p(self.g_w_rows),
-            _p(self.n_uniq), 0, st), "rec_deepfm_fused_post_f32")
-
-    def _enqueue(self, cols, label, t, cur, have_plan, next_cols):
-        """One step.  cur: plan buffer of this batch; have_plan: it was filled by the previous step; next_cols: columns
-        of the next batch, whose plan is built into buffer cur+1 concurrently (second stream).  The fork point is an
-        event recorded BEFORE the fused kernel is enqueued, and the fused kernel is enqueued first: in a captured graph
-        both branches are roots and the runtime starts them in creation order with ~15 us between them -- the kernel of
-        the critical path must go first."""
-        main = torch.cuda.current_stream()
-        side = self.side_stream
-        forked = (not have_plan) or (next_cols is not None)
-        if forked:
-            fork_ev = torch.cuda.Event()
-            fork_ev.record(main)                                 # a sort only needs ids: nothing of this step
-        st = C.c_void_p(main.cuda_stream)
-        self._launch_main(cols, label, st)
-        if forked:
-            side.wait_event(fork_ev)
-            if not have_plan:
-                self._sort(cols, cur, side)                      # this batch's own plan (non-pipelined call)
-                main.wait_stream(side)                           # ... is needed now
-            if next_cols is not None:
-                self._sort(next_cols, (cur + 1) % self.NBUF, side)   # the next batch's plan
-        self._launch_post(cur, st)
-        if self.optimizer is not None:
-            self._optimizer(t, st)
-        if next_cols is not None:
-            main.wait_stream(side)                               # join: the next step relies on the other buffer
+            _p(self.n_uniq), st), "rec_deepfm_fused_post_direct_f32")
 
     def _optimizer(self, t, st):
         lr, b1, b2, eps = self.lr, 0.9, 0.999, 1e-7
@@ -442,116 +438,97 @@ class DeepFMFusedStep:
         """One train_loop iteration on `inputs`.  ``next_inputs`` (optional) = the batch of the NEXT call: its
         de-duplication plan is built on the second stream while this batch is differentiated (input-pipeline style
         prefetch: the plan depends on ids only).  Without it, or when the previous call did not announce this batch,
-        the plan is built inside this call."""
-        cols = self._cols(inputs)
-        y = inputs[label_name]
-        if y.dtype != torch.float32 or not y.is_cuda or y.numel() != self.B or not y.is_contiguous():
-            raise ValueError("label must be a contiguous float32 CUDA tensor with %d entries" % self.B)
-        next_cols = self._cols(next_inputs) if next_inputs is not None else None
-        key = tuple(c.data_ptr() for c in cols)
-        next_key = tuple(c.data_ptr() for c in next_cols) if next_cols is not None else None
-        have_plan = self._plan_key is not None and self._plan_key == key
-        cur = self._plan_buf if have_plan else 0
-        self.t += 1
-        if not self.use_graph or self.optimizer is not None:
-            self._enqueue(cols, y, self.t, cur, have_plan, next_cols)
+        the plan is built inside this call, in front of the fused kernel."""
+        return self.many([inputs], label_name, then=next_inputs)
+
+    def _key(self, cols):
+        return tuple(c.data_ptr() for c in cols)
+
+    def many(self, batches, label_name="label", then=None):
+        """len(batches) consecutive train_loop iterations; with ``use_graph`` as ONE hipGraph replay (a launch-bound
+        inner loop: one graph launch costs ~20 us of idle GPU).  ``then``: the batch, or the list of batches, of the NEXT
+        call -- their de-duplication plans are built on the second stream beside this call's steps, so that no fused
+        kernel of the next call waits for a sort (the plan has to be complete before the kernel starts: direct mode).
+        A batch of this call that no earlier call announced is sorted in line.  Results left in the buffers are the last
+        step's; gradients are to be consumed by an optimizer in the same call or after single-step calls."""
+        half = self.NBUF // 2
+        if then is None:
+            then_list = []
+        elif isinstance(then, dict):
+            then_list = [then]
         else:
-            gkey = (key, y.data_ptr(), next_key, cur, have_plan)
+            then_list = list(then)
+        if len(batches) > half or len(then_list) > half:
+            raise ValueError("many(): at most %d batches per call (and per announcement)" % half)
+        seq = []
+        for b in batches:
+            y = b[label_name]
+            if y.dtype != torch.float32 or not y.is_cuda or y.numel() != self.B or not y.is_contiguous():
+                raise ValueError("label must be a contiguous float32 CUDA tensor with %d entries" % self.B)
+            seq.append((self._cols(b), y))
+        then_cols = [self._cols(b) for b in then_list]
+        keys = [self._key(cols) for cols, _ in seq]
+        then_keys = [self._key(cols) for cols in then_cols]
+        n = len(seq)
+        # plan buffers: the ring has two halves.  Plans announced by the previous call live in half `cur_half`; batches
+        # of this call that were not announced take the free slots of the same half; the announced batches of the next
+        # call go to the other half
+        cur_half = self._half
+        pre = self._prefetched
+        used = set(pre[k] for k in keys if k in pre)
+        free = [cur_half * half + j for j in range(half) if cur_half * half + j not in used]
+        bufs, inline = [], []
+        for i, k in enumerate(keys):
+            if k in pre and pre[k] not in bufs:
+                bufs.append(pre[k])
+            else:
+                bufs.append(free.pop(0))
+                inline.append(i)
+        other = (1 - cur_half) * half
+        then_bufs = [other + j for j in range(len(then_cols))]
+        graphed = self.use_graph and self.optimizer is None
+        gkey = (tuple(keys), tuple(y.data_ptr() for _, y in seq), tuple(then_keys), tuple(bufs), tuple(inline))
+
+        def enqueue_all():
+            main, side = torch.cuda.current_stream(), self.side_stream
+            st = C.c_void_p(main.cuda_stream)
+            for i in inline:                                     # not announced: sorted in line, all of them BEFORE the
+                self._sort(seq[i][0], bufs[i], main)             # second stream starts (the sorts share one workspace)
+            if then_cols:
+                start_ev = torch.cuda.Event()
+                start_ev.record(main)                            # a sort only needs ids: nothing of this call
+            self._launch_main(seq[0][0], seq[0][1], st, bufs[0])  # the critical path's first kernel goes first
+            if then_cols:
+                side.wait_event(start_ev)
+                for j in range(0, len(then_cols), self.GROUP):   # GROUP batches (consecutive buffers) per sort call
+                    self._sort_group(then_cols[j:j + self.GROUP], then_bufs[j], side)
+            for i in range(n):
+                if i > 0:
+                    self._launch_main(seq[i][0], seq[i][1], st, bufs[i])
+                self._launch_post(bufs[i], st)
+                if self.optimizer is not None:
+                    self.t += 1
+                    self._optimizer(self.t, st)
+            if then_cols:
+                main.wait_stream(side)                           # join: the next call relies on the other half
+
+        if not graphed:
+            enqueue_all()
+        else:
             ent = self._graphs.get(gkey)
             if ent is None:
-                self._enqueue(cols, y, self.t, cur, have_plan, next_cols)   # warm-up (sets the kernel attributes)
+                enqueue_all()                                    # warm-up (sets the kernel attributes)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    self._enqueue(cols, y, self.t, cur, have_plan, next_cols)
-                ent = (g, cols, y, next_cols)                    # keep the inputs alive: the graph holds addresses
+                    enqueue_all()
+                ent = (g, seq, then_cols)                        # keep the inputs alive: the graph holds addresses
                 self._graphs[gkey] = ent
             ent[0].replay()
-        if next_cols is not None:
-            self._plan_key, self._plan_buf = next_key, (cur + 1) % self.NBUF
-        else:
-            self._plan_key = None
-        return self.loss
-
-    def many(self, batches, label_name="label", then=None):
-        """len(batches) consecutive train_loop iterations as ONE hipGraph replay (a launch-bound inner loop: one graph
-        launch costs ~20 us of idle GPU, a third of a step).  Step i announces batch i+1; the last one announces
-        ``then`` (usually the first batch of the next call).  Results left in the buffers are the last step's;
-        gradients are to be consumed by an optimizer captured in the same graph or after single-step calls."""
-        if not self.use_graph or self.optimizer is not None:
-            for i, b in enumerate(batches):
-                nxt = batches[i + 1] if i + 1 < len(batches) else then
-                self(b, label_name, next_inputs=nxt)
-            return self.loss
-        seq = [(self._cols(b), b[label_name]) for b in batches]
-        then_cols = self._cols(then) if then is not None else None
-        keys = [tuple(c.data_ptr() for c in cols) for cols, _ in seq]
-        then_key = tuple(c.data_ptr() for c in then_cols) if then_cols is not None else None
-        have_first = self._plan_key is not None and self._plan_key == keys[0]
-        cur0 = self._plan_buf if have_first else 0
-        gkey = ("many", tuple(keys), tuple(y.data_ptr() for _, y in seq), then_key, cur0, have_first)
-
-        n = len(seq)
-        half = self.NBUF // 2
-        if n > half:
-            raise ValueError("many(): at most %d batches per call" % half)
-        # plan buffers of this call: batch 0 keeps the one it was prefetched into; batches 1..n-1 and `then` get the n
-        # consecutive buffers at the start of the OTHER half of the ring (free: the previous graph has completed)
-        base = 0 if cur0 >= half else half
-        bufs = [cur0] + [base + j for j in range(n)]
-
-        def enqueue_all():
-            """Every batch of the graph has a plan buffer of its own, so the sorts depend on nothing but the ids: they
-            are all enqueued up front on the second stream, GROUP batches per call, and run ahead of the main chain;
-            step i waits for its plan between its two launches."""
-            main, side = torch.cuda.current_stream(), self.side_stream
-            st = C.c_void_p(main.cuda_stream)
-            start_ev = torch.cuda.Event()
-            start_ev.record(main)
-            self._launch_main(seq[0][0], seq[0][1], st)          # the critical path's first kernel goes first
-            todo = ([] if have_first else [0]) + list(range(1, n)) + ([n] if then_cols is not None else [])
-            ready = {}
-            if todo:
-                side.wait_event(start_ev)
-                gi = 0
-                while gi < len(todo):
-                    grp = [todo[gi]]                             # up to GROUP batches with consecutive buffers
-                    while len(grp) < self.GROUP and gi + len(grp) < len(todo) and todo[gi + len(grp)] == grp[-1] + 1:
-                        grp.append(todo[gi + len(grp)])
-                    if grp[0] == 0:
-                        grp = grp[:1]                            # batch 0's buffer is not next to the others
-                    gi += len(grp)
-                    cl = [seq[i][0] if i < n else then_cols for i in grp]
-                    self._sort_group(cl, bufs[grp[0]], side)
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    for i in grp:
-                        ready[i] = ev
-            for i in range(n):
-                if i > 0:
-                    self._launch_main(seq[i][0], seq[i][1], st)
-                if i in ready:
-                    main.wait_event(ready[i])
-                self._launch_post(bufs[i], st)
-            if todo:
-                main.wait_stream(side)
-            return bufs[n]
-
-        ent = self._graphs.get(gkey)
-        if ent is None:
-            enqueue_all()                                        # warm-up (sets the kernel attributes)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                last = enqueue_all()
-            ent = (g, seq, then_cols, last)
-            self._graphs[gkey] = ent
-        ent[0].replay()
-        self.t += len(seq)
-        if then_cols is not None:
-            self._plan_key, self._plan_buf = then_key, ent[3]
-        else:
-            self._plan_key = None
+        if self.optimizer is None:
+            self.t += n
+        self._prefetched = dict(zip(then_keys, then_bufs))
+        self._half = 1 - cur_half if then_cols else cur_half
         return self.loss
 
     def check_flags(self):

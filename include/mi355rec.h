@@ -264,6 +264,29 @@ size_t rec_colsort_workspace_bytes(int64_t B, int F);
 int rec_colsort_plan_i64(const int64_t* const* cols_host, int F, int64_t B, int64_t V, const int64_t* col_lo,
                          int64_t max_key, int32_t* perm, int64_t* col_uid, int32_t* col_seg, int32_t* col_nu,
                          int* bad_flag, void* workspace, void* stream);
+/* The same plan plus its inverse view: dloc [F,B] (int32) = for lookup (column f, example b) the index of its run of
+ * equal ids inside the column (0 .. col_nu[f]-1), with the sign bit set unless the lookup is the FIRST member of the run
+ * (smallest example index).  What the direct mode of the fused step needs to write value rows straight to their
+ * de-duplicated slot (global slot = runs of the columns before + the run index). */
+int rec_colsort_plan_dest_i64(const int64_t* const* cols_host, int F, int64_t B, int64_t V, const int64_t* col_lo,
+                              int64_t max_key, int32_t* perm, int64_t* col_uid, int32_t* col_seg, int32_t* col_nu,
+                              int32_t* dloc, int* bad_flag, void* workspace, void* stream);
+/* Direct mode of the fused step: the plan of the batch (rec_colsort_plan_dest_i64) is complete before the launch.
+ * rec_deepfm_fused_main_direct_f32 = rec_deepfm_fused_main_f32, except that the IndexedSlices value row of a lookup that
+ * heads its run goes straight to g_embed_rows[slot] (only the other members of a run are written to vals);
+ * rec_deepfm_fused_post_direct_f32 then adds the remaining members of runs longer than one in position order (sums
+ * bit-identical to the plain path), writes uniq_ids / g_w_rows / n_uniq and the zero-padded tail, and reduces the dense
+ * partials.  Replaces the 2.FM/ModelManager.py:176-179 IndexedSlices hand-over like the plain pair of calls does. */
+int rec_deepfm_fused_main_direct_f32(const float* table, int64_t ld, int64_t V, const int64_t* const* cols_host, int F,
+                                     int64_t B, const float* bias, const float* K0, const float* b0, const float* K1,
+                                     const float* b1, const float* K2, const float* b2, const float* label, float* gz,
+                                     float* vals, float* prob, int* oob_flag, void* workspace, const int32_t* dloc,
+                                     const int32_t* col_nu, float* g_embed_rows, void* stream);
+int rec_deepfm_fused_post_direct_f32(int F, int64_t B, const float* gz, const float* vals, float* dK0, float* db0,
+                                     float* dK1, float* db1, float* dK2, float* db2, float* dbias, float* loss,
+                                     void* workspace, const int32_t* perm, const int64_t* col_uid, const int32_t* col_seg,
+                                     const int32_t* col_nu, int64_t* uniq_ids, float* g_embed_rows, float* g_w_rows,
+                                     int64_t* n_uniq, void* stream);
 /* segment sums of vals [B*F,16] (embed) and gz [B] (w) over that plan + compaction to the global ascending list:
  * uniq_ids [B*F], g_embed_rows [B*F,16], g_w_rows [B*F], n_uniq; the tail is padded like rec_dedup_plan_i64's. */
 int rec_colseg_sum_f32(const float* vals, const float* gz, const int32_t* perm, const int64_t* col_uid,

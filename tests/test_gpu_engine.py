@@ -243,11 +243,14 @@ def test_fused_step_multi_step_graph_equals_single_steps():
         out["loss"] = step.loss.clone()
         return out
 
-    for seq, then in (([0, 1, 2, 3], 0), ([0, 1, 2, 3], 0), ([2, 1], None), ([3], 1), ([1, 0, 2], None)):
+    # `then` = None, one batch, or the list of batches of the next call (all of their plans are built beside this call)
+    for seq, then in (([0, 1, 2, 3], 0), ([0, 1, 2, 3], 0), ([2, 1], None), ([3], 1), ([1, 0, 2], None),
+                      ([0, 1], [2, 3]), ([2, 3], [0, 1]), ([0, 1], [3, 2, 1]), ([3, 1, 2], [0]), ([0, 0], [0, 0]), ([0, 0], None)):
         for i in seq:
             one(devb[i])
         want = snapshot(one)
-        multi.many([devb[i] for i in seq], then=devb[then] if then is not None else None)
+        ann = None if then is None else (devb[then] if isinstance(then, int) else [devb[i] for i in then])
+        multi.many([devb[i] for i in seq], then=ann)
         multi.check_flags()
         got = snapshot(multi)
         for k in want:
