@@ -326,7 +326,7 @@ class DeepFMFusedStep:
                            col_nu=self._col_nu[b], dloc=self._dloc[b]) for b in range(NB)]
         # consecutive buffers are contiguous, so ONE sort call can build the plans of GROUP upcoming batches as
         # GROUP*F columns (the sort kernels are latency-bound at < 1 wave per SIMD: two batches cost ~1.2x one)
-        self.GROUP = max(1, min(2, 64 // F))
+        self.GROUP = max(1, min(4, 128 // F))
         self.col_lo_rep = self.col_lo.repeat(self.GROUP).contiguous()
         self._prefetched, self._half = {}, 0     # plans announced by the previous call: id-tensor addresses -> buffer
         self.uniq_ids = torch.empty(n, dtype=torch.int64, device=dev)

@@ -33,7 +33,7 @@ extern "C" {
 #define REC_E_UNSUPPORTED (-2)
 #define REC_E_WORKSPACE (-3)
 
-#define REC_MAX_COLS 64
+#define REC_MAX_COLS 128
 
 /* activation kinds shared by the dense entry points */
 enum { REC_ACT_NONE = 0, REC_ACT_RELU = 1, REC_ACT_SIGMOID = 2, REC_ACT_TANH = 3 };

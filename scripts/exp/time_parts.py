@@ -69,6 +69,12 @@ def l_sort1(n):
         fs._sort(cols[i % NB], i % NB, torch.cuda.current_stream())
 
 
+def l_sort4(n):
+    for i in range(n):
+        j = (4 * i) % NB
+        fs._sort_group([cols[j], cols[j + 1], cols[j + 2], cols[j + 3]], j, torch.cuda.current_stream())
+
+
 def l_sort2(n):
     for i in range(n):
         j = (2 * i) % NB
@@ -81,3 +87,5 @@ print("post launch          %7.2f us" % timed(l_post, 48))
 print("fused + post back to back    %7.2f us per step" % timed(l_both, 48))
 print("sort chain, one batch        %7.2f us" % timed(l_sort1, 32))
 print("sort chain, two batches      %7.2f us (per batch %.2f)" % ((lambda t: (t, t / 2))(timed(l_sort2, 16))))
+if fs.GROUP >= 4:
+    print("sort chain, four batches     %7.2f us (per batch %.2f)" % ((lambda t: (t, t / 4))(timed(l_sort4, 8))))
