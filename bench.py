@@ -291,7 +291,7 @@ def main():
     vp = lambda t: C.c_void_p(t.data_ptr())
     pmc = {}
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["kernels"]
     except (OSError, ValueError, KeyError):
         pass
 
@@ -338,6 +338,45 @@ def main():
                            "= 3.9 TB/s, so the ceiling of this kernel is ~0.29 of the 8 TB/s spec in algorithmic bytes; "
                            "every timed launch here takes another resident batch (no reuse through L2 / the 256-MB "
                            "memory-side cache)")
+    roofline_gather["physical_frac"] = (roofline_gather["traffic"] / (roofline_gather["avg_launch_us"] * 1e-6) / 1e9 /
+                                        HBM_PEAK_GBS) if roofline_gather["traffic"] else None
+
+    # (1b) the plain row gather at the row widths of the other configs, where the 128-byte-line granularity no longer
+    # halves the useful bytes: E = 32 (128-B rows, V = 10M: config C) and E = 64 (256-B rows, V = 100M: config D).
+    # Algorithmic bytes per lookup (materialising gather): 8 (id) + 2 * 4E (row read + row written).
+    def gather_record(Eg, Vg, n_cfg, cfg_name):
+        tab = torch.empty((Vg, Eg), dtype=torch.float32, device="cuda")
+        tab.uniform_(-0.05, 0.05)                     # every page written: an untouched allocation reads unrealistically fast
+        n_big = 1 << 20
+        rs = np.random.Generator(np.random.PCG64(Eg))
+        idsets = [torch.from_numpy(rs.integers(0, Vg, size=n_big)).cuda() for _ in range(8)]   # fresh rows per launch
+        out = torch.empty((n_big, Eg), dtype=torch.float32, device="cuda")
+        rec = {}
+        for key, n_l in (("asymptote", n_big), ("config", n_cfg)):
+            def launch(n, n_l=n_l):
+                st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                for i in range(n):
+                    check(lib.rec_emb_gather_f32(vp(tab), Vg, Eg, Eg, vp(idsets[i % 8]), n_l, vp(out), None, st),
+                          "rec_emb_gather_f32")
+            us = timed(launch, 40)
+            nbytes = n_l * (8 + 2 * 4 * Eg)
+            rec[key] = {"n_lookups": n_l, "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": us,
+                        "achieved": nbytes / (us * 1e-6) / 1e9, "frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+        tkey = "gather_rows_kernel_e%d" % Eg
+        traffic = pmc[tkey]["hbm_bytes_per_launch_corrected"] if tkey in pmc else None
+        a = rec["asymptote"]
+        res = {"bound": "hbm", "kernel": "gather_rows_kernel<%d,4> (rec_emb_gather_f32, %d-byte rows, table %d x %dd)"
+               % (Eg // 4, 4 * Eg, Vg, Eg), "achieved": a["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": a["frac"], "traffic": traffic,
+               "physical_frac": (traffic / (a["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+               "n_lookups": a["n_lookups"], "algorithmic_bytes_per_launch": a["algorithmic_bytes_per_launch"],
+               "avg_launch_us": a["avg_launch_us"], "at_config_size": dict(rec["config"], config=cfg_name)}
+        del tab, out, idsets
+        torch.cuda.empty_cache()
+        return res
+
+    roofline_gather_e32 = gather_record(32, 10_000_000, 16384 * 10, "C: B=16384 x 10 categorical fields")
+    roofline_gather_e64 = gather_record(64, 100_000_000, 8192 * 3, "D: B=8192 x 3 item fields")
     roofline = roofline_gather
     if not args.generic:
         # (2) the dominant kernel of the timed step: the fused forward+backward kernel.  Algorithmic bytes: the gather
@@ -399,7 +438,8 @@ def main():
                           "fused: fwd+bwd kernel writing value rows straight to their de-duplicated slots (plan complete "
                           "before the kernel), then reduction + remaining segment sums in one launch; de-duplication "
                           "plan of batch k+1 (per-column sort, second stream) overlaps step k"},
-               "roofline": roofline, "roofline_gather": roofline_gather, "loss": loss}
+               "roofline": roofline, "roofline_gather": roofline_gather, "roofline_gather_e32": roofline_gather_e32,
+               "roofline_gather_e64": roofline_gather_e64, "loss": loss}
         if replicas is not None:
             out["replicas_no_exchange"] = replicas
         out.update(extra)

@@ -69,6 +69,39 @@ __global__ __launch_bounds__(256) void gather_vec4_kernel(const float* __restric
   out[t] = v;
 }
 
+// Power-of-two rows (E = 4, 8, ..., 256: every embedding width of BASELINE.json's configs): LPR lanes x 16 B cover a
+// row, so a wave instruction reads 64/LPR whole rows; each thread has UNR independent row loads in flight (ids first,
+// then all rows, then all stores) and the row / lane split is a shift, not a 64-bit division.
+template <int LPR, int UNR>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, int64_t V, int64_t ld,
+                                                          const int64_t* __restrict__ idx, int64_t n,
+                                                          float4* __restrict__ out, int* oob) {
+  constexpr int R = 256 / LPR;                       // rows per workgroup pass
+  const int c = threadIdx.x & (LPR - 1), rs = threadIdx.x / LPR;
+  const int64_t r0 = (int64_t)blockIdx.x * (R * UNR) + rs;
+  int64_t id[UNR];
+#pragma unroll
+  for (int j = 0; j < UNR; ++j) {
+    const int64_t r = r0 + (int64_t)j * R;
+    id[j] = r < n ? idx[r] : -1;
+  }
+  float4 v[UNR];
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < UNR; ++j) {
+    const bool ok = (uint64_t)id[j] < (uint64_t)V;
+    bad |= !ok && (r0 + (int64_t)j * R < n);
+    v[j] = *reinterpret_cast<const float4*>(table + (ok ? id[j] : 0) * ld + 4 * c);
+    if (!ok) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (bad && oob) *oob = 1;
+#pragma unroll
+  for (int j = 0; j < UNR; ++j) {
+    const int64_t r = r0 + (int64_t)j * R;
+    if (r < n) out[r * LPR + c] = v[j];
+  }
+}
+
 __global__ __launch_bounds__(256) void gather_scalar_kernel(const float* __restrict__ table, int64_t V, int E,
                                                             int64_t ld, const int64_t* __restrict__ idx, int64_t n,
                                                             float* __restrict__ out, int* oob) {
@@ -95,7 +128,24 @@ extern "C" int rec_emb_gather_f32(const float* table, int64_t V, int E, int64_t 
   if (V <= 0 || E <= 0 || ld < E || n < 0) return REC_E_ARG;
   if (n == 0) return REC_OK;
   if (!table || !idx || !out) return REC_E_ARG;
-  if (vec4_ok(table, E, ld) && vec4_ok(out, E, E)) {
+  if (vec4_ok(table, E, ld) && vec4_ok(out, E, E) && (E & (E - 1)) == 0 && E >= 4 && E <= 256) {
+    const int lpr = E / 4;
+    constexpr int UNR = 4;
+    const unsigned grid = (unsigned)ceil_div64(n, (256 / lpr) * UNR);
+#define GATHER_ROWS(L)                                                                                           \
+  hipLaunchKernelGGL((gather_rows_kernel<L, UNR>), dim3(grid), dim3(256), 0, as_stream(stream), table, V, ld, idx, n, \
+                     (float4*)out, oob_flag)
+    switch (lpr) {
+      case 1: GATHER_ROWS(1); break;
+      case 2: GATHER_ROWS(2); break;
+      case 4: GATHER_ROWS(4); break;
+      case 8: GATHER_ROWS(8); break;
+      case 16: GATHER_ROWS(16); break;
+      case 32: GATHER_ROWS(32); break;
+      default: GATHER_ROWS(64); break;
+    }
+#undef GATHER_ROWS
+  } else if (vec4_ok(table, E, ld) && vec4_ok(out, E, E)) {
     int lpr = E / 4;
     hipLaunchKernelGGL(gather_vec4_kernel, dim3((unsigned)ceil_div64(n * lpr, 256)), dim3(256), 0,
                        as_stream(stream), table, V, lpr, ld, idx, n, (float4*)out, oob_flag);
