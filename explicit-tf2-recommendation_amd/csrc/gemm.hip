@@ -253,6 +253,283 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_big_kernel(int64_t M, int64_t
     }
 }
 
+// ---- row-panel variant for a tall product with a modest N (CrossNet matrix mode: M = batch 16384, N = K = 323 / 835;
+// every layer of it and its dX = H.W backward): ONE workgroup owns 64 rows x ALL N columns, so the grid is M/64
+// workgroups -- exactly one per CU at M = 16384 -- and every CU multiplies the same number of 32x32 blocks (a 128x128
+// tiling of [16384, 835] leaves 896 tiles for 256 CUs: a fourth round that is 17 % full, and 7 % of padding columns).
+// 8 waves = 2 row blocks x 4 column groups; column block j belongs to group j & 3, a wave holds up to 7 accumulator
+// tiles (112 VGPRs) and reads 1 A + up to 7 B operands per 2-deep k step.  A (64 x 16) and B (16 x N) slabs are
+// double-buffered in LDS (k-major, conflict-free operand reads), the next slab's global loads are in flight while the
+// current one is multiplied (one barrier per slab).  B is re-read from L2 by every workgroup (N*K*4 bytes <= 2.8 MB).
+constexpr int PNB = 28, PPAD = 4;      // max column blocks (N <= 896), LDS row pad
+
+// PMt rows per workgroup (32 or 64), PKt slab depth, MAXB column blocks per wave; threads = PMt * 8 (waves = PMt/32 row
+// blocks x 4 column groups).  <64,16>: one 8-wave workgroup per CU with 124 KB of LDS; <32,8>: two 4-wave workgroups
+// per CU (60 KB each) whose barriers and staging phases overlap each other's MFMAs.
+template <int TA, int TB, int MAXB, int PMt, int PKt>
+__global__ __launch_bounds__(PMt * 8) void gemm_f32_panel_kernel(int64_t M, int64_t N, int64_t Kall,
+                                                                 const float* __restrict__ A, int64_t lda,
+                                                                 const float* __restrict__ B, int64_t ldb,
+                                                                 float* __restrict__ C, int64_t ldc, int epi,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ e0, int64_t lde0,
+                                                                 const float* __restrict__ e1, int64_t lde1,
+                                                                 float* __restrict__ aux, int64_t kchunk,
+                                                                 float* __restrict__ ws) {
+  // split-K (weight gradient H^T.X: M = N = D, K = batch): blockIdx.y takes k in [kb, kb + K) and leaves its partial in
+  // ws[blockIdx.y]; splitk_reduce_kernel adds the slices in order.  Inside the kernel K and the operand pointers are
+  // those of the slice.
+  const int64_t kb = (int64_t)blockIdx.y * kchunk;
+  const int64_t K = (kb + kchunk < Kall ? kb + kchunk : Kall) - kb;
+  A += TA ? kb * lda : kb;
+  B += TB ? kb : kb * ldb;
+  // every wave multiplies exactly MAXB blocks per k step (no guards around the MFMAs); blocks beyond ceil(N/32) read
+  // zero columns of the slab
+  extern __shared__ __attribute__((aligned(16))) float plds[];
+  constexpr int NTH = PMt * 8;
+  constexpr int NP = MAXB * 4 * 32;                  // padded column count
+  constexpr int bs = NP + PPAD;                      // row stride of a B slab
+  constexpr int as_ld = PMt + PPAD;
+  constexpr int KQ = PKt / 4;                        // float4 pieces along k
+  float* As = plds;                                  // [2][PKt][as_ld]
+  float* Bs = plds + 2 * PKt * as_ld;                // [2][PKt][bs]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % (PMt / 32), wn = wave / (PMt / 32);
+  const int lo = lane & 31, hi = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * PMt;
+  f32x16 acc[MAXB];
+#pragma unroll
+  for (int j = 0; j < MAXB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // global -> register staging of one slab.  A (row-major): PMt rows x PKt k as float4 pieces along k.  B, TB = 1
+  // (B[k][n] = Bm[n][k], rows of K contiguous): float4 along k, item = (n, k4).  B, TB = 0 (B[k][n] = Bm[k][n], rows of N
+  // contiguous): one float per item, for every k of the slab the thread takes columns tid, tid + NTH, ...
+  // Loads are unconditional (clamped addresses; what lies outside M x N never reaches the result) and 16 bytes wide at
+  // 4-byte alignment (rows of an odd K = 323 / 835 start anywhere): a guarded element-wise load would put a branch
+  // around every load and wait for each before the next.  Only the last, partial slab takes the element-wise path.
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  constexpr int BMAX = (NP * KQ + NTH - 1) / NTH;    // float4 items per thread, TB = 1
+  constexpr int NC = (NP + NTH - 1) / NTH;           // columns per thread, TB = 0
+  constexpr int AITEMS = PMt * KQ;                   // TA = 0: float4 pieces of the A slab
+  constexpr int AT = (PMt * PKt + NTH - 1) / NTH;    // TA = 1: floats per thread (A is k-major in memory: [K][M])
+  float4 ra;
+  float rat[TA ? AT : 1];
+  float4 rbv[TB ? BMAX : 1];
+  float rbs[TB ? 1 : PKt][TB ? 1 : NC];
+  const int n_items = (int)N * KQ;                   // TB = 1
+  const int am = tid / KQ, ak4 = (tid % KQ) * 4;
+  const float* arow = TA ? A : A + (m0 + am < M ? m0 + am : M - 1) * lda;
+  const int tm = tid % PMt, tk = tid / PMt;          // TA = 1: column m and first k row of this thread
+  const int64_t tmc = m0 + tm < M ? m0 + tm : M - 1;
+  int bc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) bc[c] = tid + c * NTH < (int)N ? tid + c * NTH : (int)N - 1;
+  // The staging work of a slab is cut into NCH = PKt/2 chunks, one per k step of the multiply loop: chunk c writes its
+  // share of the NEXT slab (held in registers since the slab before) to the other LDS buffer and at once re-issues the
+  // global loads of the slab after that into the same registers.  Placed between the MFMA groups, the LDS writes, the
+  // loads and their address arithmetic run under the matrix pipe instead of after it (all eight waves stage at the same
+  // time -- behind the one barrier per slab -- so nothing else would hide them).  The pipelined loop only sees FULL
+  // slabs and has no data-dependent branch (a slab index past the end is clamped to the last full slab: loaded again,
+  // staged into a buffer nobody reads); the K % PKt tail is one plain, guarded step after it.
+  constexpr int NCH = PKt / 2;
+  constexpr int BPC = (BMAX + NCH - 1) / NCH;        // TB = 1: float4 items per chunk
+  constexpr int KPC = PKt / NCH;                     // TB = 0: k rows per chunk (= 2)
+  auto fetch_chunk = [&](int64_t k0, int c) {
+    if (TA) {
+      if (c == NCH - 1) {
+#pragma unroll
+        for (int q = 0; q < AT; ++q) rat[q] = A[(k0 + tk + q * (NTH / PMt)) * lda + tmc];
+      }
+    } else if (c == NCH - 1 && tid < AITEMS) {
+      const f32x4u v = *reinterpret_cast<const f32x4u*>(arow + k0 + ak4);
+      ra = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    if (TB) {
+#pragma unroll
+      for (int q = 0; q < BPC; ++q) {
+        const int i = c * BPC + q;
+        if (i < BMAX) {
+          const int it = tid + i * NTH;
+          const int itc = it < n_items ? it : n_items - 1;
+          const int n = itc / KQ, k4 = (itc % KQ) * 4;
+          const f32x4u v = *reinterpret_cast<const f32x4u*>(B + (int64_t)n * ldb + k0 + k4);
+          rbv[i] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < KPC; ++q) {
+        const int k = c * KPC + q;
+        const float* p = B + (k0 + k) * ldb;
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) rbs[k][cc] = p[bc[cc]];
+      }
+    }
+  };
+  auto stage_chunk = [&](int buf, int c) {
+    float* as = As + buf * PKt * as_ld;
+    float* bsb = Bs + buf * PKt * bs;
+    if (TA) {
+      if (c == NCH - 1) {
+#pragma unroll
+        for (int q = 0; q < AT; ++q) as[(tk + q * (NTH / PMt)) * as_ld + tm] = rat[q];
+      }
+    } else if (c == NCH - 1 && tid < AITEMS) {
+      as[(ak4 + 0) * as_ld + am] = ra.x;
+      as[(ak4 + 1) * as_ld + am] = ra.y;
+      as[(ak4 + 2) * as_ld + am] = ra.z;
+      as[(ak4 + 3) * as_ld + am] = ra.w;
+    }
+    if (TB) {
+#pragma unroll
+      for (int q = 0; q < BPC; ++q) {
+        const int i = c * BPC + q;
+        const int it = tid + i * NTH;
+        if (i < BMAX && it < n_items) {
+          const int n = it / KQ, k4 = (it % KQ) * 4;
+          bsb[(k4 + 0) * bs + n] = rbv[i].x;
+          bsb[(k4 + 1) * bs + n] = rbv[i].y;
+          bsb[(k4 + 2) * bs + n] = rbv[i].z;
+          bsb[(k4 + 3) * bs + n] = rbv[i].w;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < KPC; ++q) {
+        const int k = c * KPC + q;
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc)
+          if (tid + cc * NTH < (int)N) bsb[k * bs + tid + cc * NTH] = rbs[k][cc];
+      }
+    }
+  };
+  // columns N .. NP-1 of both B buffers are read by the last column blocks and never staged: zero them once
+  for (int i = tid; i < 2 * PKt * (NP - (int)N); i += NTH) {
+    const int r = i / (NP - (int)N), cix = i - r * (NP - (int)N);
+    Bs[r * bs + (int)N + cix] = 0.f;
+  }
+
+  // multiply one slab out of LDS buffer `buf`; operands of k step s+1 are read while the MFMAs of step s issue
+  // (explicit two-deep register pipeline); hook(c) runs behind the MFMA group of k step c
+  auto multiply = [&](int buf, auto hook) {
+    const float* as = As + buf * PKt * as_ld + wm * 32 + lo;
+    const float* bsb = Bs + buf * PKt * bs + wn * 32 + lo;
+    float a_c = as[hi * as_ld], b_c[MAXB];
+#pragma unroll
+    for (int j = 0; j < MAXB; ++j) b_c[j] = bsb[hi * bs + j * 128];
+#pragma unroll
+    for (int kk = 0; kk < PKt; kk += 2) {
+      float a_n = 0.f, b_n[MAXB];
+      if (kk + 2 < PKt) {
+        a_n = as[(kk + 2 + hi) * as_ld];
+#pragma unroll
+        for (int j = 0; j < MAXB; ++j) b_n[j] = bsb[(kk + 2 + hi) * bs + j * 128];
+      }
+      __builtin_amdgcn_sched_barrier(0);               // keep the reads above in front of this step's MFMAs
+#pragma unroll
+      for (int j = 0; j < MAXB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, b_c[j], acc[j], 0, 0, 0);
+      hook(kk >> 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk + 2 < PKt) {
+        a_c = a_n;
+#pragma unroll
+        for (int j = 0; j < MAXB; ++j) b_c[j] = b_n[j];
+      }
+    }
+  };
+
+  const int64_t Kfull = (K / PKt) * PKt;
+  int buf = 0;
+  if (Kfull > 0) {
+    const int64_t klast = Kfull - PKt;
+    // prologue: slab 0 -> LDS buffer 0, slab 1 -> registers
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) fetch_chunk(0, c);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) stage_chunk(0, c);
+    {
+      const int64_t k1 = PKt < klast ? PKt : klast;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) fetch_chunk(k1, c);
+    }
+    __syncthreads();
+    for (int64_t k0 = 0; k0 < Kfull; k0 += PKt) {
+      const int64_t k2 = k0 + 2 * PKt < klast ? k0 + 2 * PKt : klast;
+      multiply(buf, [&](int c) {
+        stage_chunk(buf ^ 1, c);                         // next slab: registers -> the other buffer (free since the barrier)
+        fetch_chunk(k2, c);                              // the slab after next into the freed registers
+      });
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  if (Kfull < K) {
+    // tail slab (K % PKt deep): guarded element-wise loads straight to LDS, zero beyond K
+    float* as = As + buf * PKt * as_ld;
+    float* bsb = Bs + buf * PKt * bs;
+    for (int i = tid; i < PMt * PKt; i += NTH) {
+      const int m = i / PKt, k = i - m * PKt;
+      const int64_t gm = m0 + m, gk = Kfull + k;
+      as[k * as_ld + m] = (gm < M && gk < K) ? (TA ? A[gk * lda + gm] : A[gm * lda + gk]) : 0.f;
+    }
+    for (int i = tid; i < PKt * (int)N; i += NTH) {
+      int k, n;
+      if (TB) { n = i / PKt; k = i - n * PKt; } else { k = i / (int)N; n = i - k * (int)N; }
+      const int64_t gk = Kfull + k;
+      bsb[k * bs + n] = gk < K ? (TB ? B[(int64_t)n * ldb + gk] : B[gk * ldb + n]) : 0.f;
+    }
+    __syncthreads();
+    multiply(buf, [](int) {});
+  }
+
+  // epilogue, one column block at a time: the kind is tested once per block (not per element), the side operands of
+  // the block's 16 rows are all requested before the first is used, addresses are clamped instead of guarded
+#pragma unroll
+  for (int j = 0; j < MAXB; ++j) {
+    const int64_t gn = (int64_t)(wn + 4 * j) * 32 + lo;
+    const bool cok = gn < N;
+    const int64_t gnc = cok ? gn : N - 1;
+    const int64_t mb = m0 + wm * 32 + 4 * hi;                  // row of register r: mb + (r&3) + 8*(r>>2)
+    if (ws) {                                                  // split-K slice: plain partial, no epilogue
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t gm = mb + (r & 3) + 8 * (r >> 2);
+        if (gm < M && cok) ws[((int64_t)blockIdx.y * M + gm) * N + gn] = acc[j][r];
+      }
+      continue;
+    }
+    const float bj = (epi >= REC_EPI_BIAS && epi <= REC_EPI_CROSS) ? bias[gnc] : 0.f;
+    float x0[16], x1[16];
+    if (epi == REC_EPI_CROSS || epi == REC_EPI_ADD) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int64_t gm = mb + (r & 3) + 8 * (r >> 2);
+        gm = gm < M ? gm : M - 1;
+        x1[r] = e1[gm * lde1 + gnc];
+        x0[r] = epi == REC_EPI_CROSS ? e0[gm * lde0 + gnc] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t gm = mb + (r & 3) + 8 * (r >> 2);
+      const float u = acc[j][r] + bj;
+      float v = u;
+      if (epi == REC_EPI_BIAS_RELU) v = fmaxf(u, 0.f);
+      else if (epi == REC_EPI_BIAS_SIGMOID) v = sigmoid_acc(u);
+      else if (epi == REC_EPI_BIAS_TANH) v = tanhf(u);
+      else if (epi == REC_EPI_CROSS) v = x0[r] * u + x1[r];
+      else if (epi == REC_EPI_ADD) v = u + x1[r];
+      if (gm < M && cok) {
+        if (epi == REC_EPI_CROSS && aux) aux[gm * ldc + gn] = u;
+        C[gm * ldc + gn] = v;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int split, int64_t M,
                                                             int64_t N, float* __restrict__ C, int64_t ldc, int epi,
                                                             const float* __restrict__ bias, const float* __restrict__ e0,
@@ -314,6 +591,60 @@ extern "C" int rec_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
       hipLaunchKernelGGL((gemm_f32_skinny_kernel<2>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc,
                          epilogue_kind, bias, e0, lde0, e1, lde1, aux);
     REC_LAUNCH_CHECK();
+    return REC_OK;
+  }
+  // row panels x all N: a tall product with a modest N and row-major A (CrossNet matrix mode and its dX, split_k = 1), or
+  // its weight gradient H^T.X (A k-major, M and N modest, K = batch): there the panels are multiplied by K slices so
+  // that every CU gets one workgroup, and the slices are added in order
+  const bool panel_fwd = !transA && split_k == 1 && N > 64 && N <= PNB * 32 && M >= 64 * 128;
+  // (measured and not taken: M = N = 835, K = 16384 as 14 panels x 19 K slices ran 456 us against 358 us on the 128x128
+  // split-K tiles -- every slice's 2.9 MB of X is fetched by the L2 of each of the 8 XCDs its 14 panels land on)
+  const bool panel_wg = false;
+  if (panel_fwd || panel_wg) {
+    const int maxb = (int)ceil_div64(ceil_div64(N, 32), 4);            // column blocks per wave, 1..7
+    constexpr int PMt = 64, PKt = 16;
+    const size_t lds = sizeof(float) * (2 * PKt * (PMt + PPAD) + 2 * PKt * ((size_t)maxb * 128 + PPAD));
+    const int64_t panels = ceil_div64(M, PMt);
+    int psplit = 1;
+    int64_t pchunk = K;
+    float* pws = nullptr;
+    if (panel_wg) {
+      psplit = split_k;                              // the caller's (ops.split_k_for: ~ one workgroup per CU)
+      pchunk = ((ceil_div64(K, psplit) + PKt - 1) / PKt) * PKt;
+      psplit = (int)ceil_div64(K, pchunk);
+      if (psplit > 1) {
+        if (!workspace || psplit > split_k) return REC_E_WORKSPACE;    // the caller sizes ws for split_k slices
+        pws = workspace;
+      }
+    }
+    dim3 grid((unsigned)panels, (unsigned)psplit);
+#define PANEL(TAv, TBv, MB)                                                                                          \
+  do {                                                                                                               \
+    hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_panel_kernel<TAv, TBv, MB, PMt, PKt>), \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+    if (e_ != hipSuccess) return (int)e_;                                                                            \
+    hipLaunchKernelGGL((gemm_f32_panel_kernel<TAv, TBv, MB, PMt, PKt>), grid, dim3(PMt * 8), lds, st, M, N, K, A, lda, \
+                       B, ldb, C, ldc, epilogue_kind, bias, e0, lde0, e1, lde1, aux, pchunk, pws);                   \
+  } while (0)
+#define PANEL_MB(TAv, TBv)                                                                                           \
+  switch (maxb) {                                                                                                    \
+    case 1: PANEL(TAv, TBv, 1); break;                                                                               \
+    case 2: PANEL(TAv, TBv, 2); break;                                                                               \
+    case 3: PANEL(TAv, TBv, 3); break;                                                                               \
+    case 4: PANEL(TAv, TBv, 4); break;                                                                               \
+    case 5: PANEL(TAv, TBv, 5); break;                                                                               \
+    case 6: PANEL(TAv, TBv, 6); break;                                                                               \
+    default: PANEL(TAv, TBv, 7); break;                                                                              \
+  }
+    if (panel_wg) { PANEL_MB(1, 0); } else if (transB) { PANEL_MB(0, 1); } else { PANEL_MB(0, 0); }
+#undef PANEL_MB
+#undef PANEL
+    REC_LAUNCH_CHECK();
+    if (pws) {
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div64(M * N, 256)), dim3(256), 0, st, pws, psplit, M,
+                         N, C, ldc, epilogue_kind, bias, e0, lde0, e1, lde1, aux);
+      REC_LAUNCH_CHECK();
+    }
     return REC_OK;
   }
   if (big) {

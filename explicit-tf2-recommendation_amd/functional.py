@@ -143,7 +143,7 @@ class LinearAct(torch.autograd.Function):
         M, Kd = x.shape
         N = K.shape[1]
         gx = ops.gemm(dpre, K, transB=True) if ctx.needs_input_grad[0] else None
-        gK = ops.gemm(x, dpre, transA=True, split_k=ops.split_k_for(M, Kd, N))
+        gK = ops.gemm(x, dpre, transA=True, split_k=ops.split_k_for(M, Kd, N, True, False))
         gb = ops.colsum(dpre) if ctx.has_bias else None
         return gx, gK, gb, None
 
@@ -197,7 +197,7 @@ class CrossMat(torch.autograd.Function):
             xl = xs[l]
             u = us[l]
             h = ops.crossnet_mat_bwd_elem(g, x0, u, gx0, accumulate=(l != L - 1))   # H = G(.)X0 ; dX0 += G(.)U
-            ops.gemm(h, xl, transA=True, split_k=ops.split_k_for(B, D, D), out=dW[l])
+            ops.gemm(h, xl, transA=True, split_k=ops.split_k_for(B, D, D, True, False), out=dW[l])
             ops.colsum(h, out=db[l])
             g = ops.gemm(h, W[l], epi=ops.EPI_ADD, e1=g)                             # dX_l = G + H W
         if L == 0:
@@ -345,7 +345,7 @@ class DinAttention(torch.autograd.Function):
                                                              padding_index, mask_valid, scores, gpooled.contiguous(),
                                                              gkeys=dst)
         gq = ops.gemm(gMext, Wcat, transB=True)                                          # [B,D]
-        gWcat = ops.gemm(q, gMext, transA=True, split_k=ops.split_k_for(B, D, D * H + H))  # [D, D*H+H]
+        gWcat = ops.gemm(q, gMext, transA=True, split_k=ops.split_k_for(B, D, D * H + H, True, False))  # [D, D*H+H]
         gbext = ops.colsum(gMext)
         gWkd = gbext[:D * H].reshape(D, H)                    # Eff_b = Wkd + M_b  =>  dWkd = sum_b dEff_b: the leading
                                                               # D*H column sums of gMext, already in gbext

@@ -212,7 +212,7 @@ def gemm(A, B, transA=False, transB=False, epi=EPI_NONE, bias=None, e0=None, e1=
                              % (M, N, out.stride(0), tuple(aux.stride())))
     if split_k is None:
         skinny = (not transA) and (not transB) and N <= 64 and M >= 256      # the no-LDS kernel splits K over its waves
-        split_k = 1 if skinny else split_k_for(K, M, N)
+        split_k = 1 if skinny else split_k_for(K, M, N, transA, transB)
     ws = None
     if split_k > 1:
         ws = torch.empty((split_k, M, N), dtype=torch.float32, device=A.device)
@@ -267,7 +267,7 @@ def copy_cols(src, dst_view):
     return dst_view
 
 
-def split_k_for(K, M, N):
+def split_k_for(K, M, N, transA=False, transB=False):
     """Heuristic split of a reduction over the batch so that ~768 workgroups run.  The 64x64 kernel spends ~2 us per
     16-deep k step (no prefetch), so a few-tile weight gradient [M,N] = X^T dY with K = batch is cut down to 64-deep
     slices (M=192, N=64, K=8192: 41 -> ~10 us); the partials are added in slice order by the split-K reduce."""

@@ -13,9 +13,12 @@ SHAPES = [  # M, N, K, transA, transB
     (4096, 96, 3492, False, True), (4096, 3492, 96, False, False), (96, 3492, 4096, True, False),
     (4096, 200, 352, False, False), (4096, 352, 200, False, True), (4096, 80, 200, False, False),
     (4096, 200, 80, False, True), (4096, 200, 192, False, False), (8192, 741, 32, False, True),
-    (16384, 323, 323, False, True), (8192, 64, 192, False, False),
+    (8192, 64, 192, False, False),
+    (16384, 323, 323, False, True), (16384, 323, 323, False, False), (323, 323, 16384, True, False),
     (16384, 835, 835, False, True), (16384, 835, 835, False, False), (835, 835, 16384, True, False),
 ]
+if len(sys.argv) > 1 and sys.argv[1] == "crossnet":
+    SHAPES = SHAPES[-6:]
 
 
 def t(fn, n=50):
