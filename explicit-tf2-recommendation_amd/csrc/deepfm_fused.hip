@@ -829,7 +829,34 @@ __global__ __launch_bounds__(256) void colsort_heads_kernel(const int64_t* __res
 struct ColSegArgs {
   const float4* vals; const float* gz; const int32_t* perm; const int64_t* col_uid; const int32_t* col_seg;
   const int32_t* col_nu; int64_t B; int F; int64_t* uniq_ids; float4* g_embed; float* g_w; int64_t* n_uniq; int packed;
+  // lazy (touched-rows) Adam applied to a row the moment its gradient is final (direct-mode post launch only; table ==
+  // null: off).  table: fused rows [V, 32] = [embed 16 | w | pad]; m_e, v_e [V,16]; m_w, v_w [V]
+  float* table; float* m_e; float* v_e; float* m_w; float* v_w; int64_t V; float lr_t, b1, b2, eps;
 };
+
+// m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2 ; var <- var - lr_t m / (sqrt(v) + eps)   (rec_adam_rows_f32's formula)
+__device__ __forceinline__ void adam_elem(float& var, float& m, float& v, float g, float lr_t, float b1, float b2,
+                                          float eps) {
+  m = m * b1 + g * (1.f - b1);
+  v = v * b2 + g * g * (1.f - b2);
+  var = var - lr_t * m / (sqrtf(v) + eps);
+}
+__device__ __forceinline__ void adam_chunk(const ColSegArgs& k, int64_t id, int c, const float4& g) {
+  float4* vp = reinterpret_cast<float4*>(k.table + id * LD) + c;
+  float4* mp = reinterpret_cast<float4*>(k.m_e + id * E16) + c;
+  float4* qp = reinterpret_cast<float4*>(k.v_e + id * E16) + c;
+  float4 x = *vp, m = *mp, v = *qp;
+  adam_elem(x.x, m.x, v.x, g.x, k.lr_t, k.b1, k.b2, k.eps);
+  adam_elem(x.y, m.y, v.y, g.y, k.lr_t, k.b1, k.b2, k.eps);
+  adam_elem(x.z, m.z, v.z, g.z, k.lr_t, k.b1, k.b2, k.eps);
+  adam_elem(x.w, m.w, v.w, g.w, k.lr_t, k.b1, k.b2, k.eps);
+  *vp = x; *mp = m; *qp = v;
+}
+__device__ __forceinline__ void adam_w(const ColSegArgs& k, int64_t id, float g) {
+  float x = k.table[id * LD + E16], m = k.m_w[id], v = k.v_w[id];
+  adam_elem(x, m, v, g, k.lr_t, k.b1, k.b2, k.eps);
+  k.table[id * LD + E16] = x; k.m_w[id] = m; k.v_w[id] = v;
+}
 
 __device__ __forceinline__ void colseg_body(const ColSegArgs& k, int bidx) {
   const float4* __restrict__ vals = k.vals;
@@ -985,8 +1012,15 @@ __device__ __forceinline__ void fixup_body(const ColSegArgs& k, int bidx) {
   }
   const int len = s1 - s0;
   const int64_t dst = before + u;
+  const bool adam = k.table != nullptr;
   if (live) {
     float accw = gz[pf[s0]];
+    const int64_t id = k.col_uid[(int64_t)f * B + u];
+    if (adam && len == 1 && (uint64_t)id < (uint64_t)k.V) {     // the row the fused kernel left is final
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) adam_chunk(k, id, cc, g_embed[dst * 4 + cc]);
+      adam_w(k, id, accw);
+    }
     if (len > 1 && len <= 8) {                                  // short run: this lane alone
       float4 a0 = g_embed[dst * 4], a1 = g_embed[dst * 4 + 1], a2 = g_embed[dst * 4 + 2], a3 = g_embed[dst * 4 + 3];
       for (int s = s0 + 1; s < s1; ++s) {
@@ -1000,9 +1034,13 @@ __device__ __forceinline__ void fixup_body(const ColSegArgs& k, int bidx) {
         accw += gz[b];
       }
       g_embed[dst * 4] = a0; g_embed[dst * 4 + 1] = a1; g_embed[dst * 4 + 2] = a2; g_embed[dst * 4 + 3] = a3;
+      if (adam && (uint64_t)id < (uint64_t)k.V) {
+        adam_chunk(k, id, 0, a0); adam_chunk(k, id, 1, a1); adam_chunk(k, id, 2, a2); adam_chunk(k, id, 3, a3);
+        adam_w(k, id, accw);
+      }
     }
     if (len <= 8) k.g_w[dst] = accw;
-    k.uniq_ids[dst] = k.col_uid[(int64_t)f * B + u];
+    k.uniq_ids[dst] = id;
   } else if (in_col) {
     // padded tail: slot = total + rank among the column's unused slots; id = the smallest id of column 0, zero rows
     const int64_t d2 = total + ((int64_t)f * B - before) + (u - nu);
@@ -1018,7 +1056,8 @@ __device__ __forceinline__ void fixup_body(const ColSegArgs& k, int bidx) {
     const int src = __ffsll((long long)longm) - 1;
     longm &= longm - 1;
     const int rs0 = __shfl(s0, src, 64), rs1 = __shfl(s1, src, 64);
-    const int64_t rdst = before + __shfl(u, src, 64);
+    const int ru = __shfl(u, src, 64);
+    const int64_t rdst = before + ru;
     float4 pa = make_float4(0.f, 0.f, 0.f, 0.f);
     float pw = 0.f;
 #pragma unroll 4
@@ -1038,7 +1077,15 @@ __device__ __forceinline__ void fixup_body(const ColSegArgs& k, int bidx) {
       float4 h = g_embed[rdst * 4 + c];
       h.x += pa.x; h.y += pa.y; h.z += pa.z; h.w += pa.w;
       g_embed[rdst * 4 + c] = h;
-      if (c == 0) k.g_w[rdst] = gz[pf[rs0]] + pw;
+      const float wsum = gz[pf[rs0]] + pw;
+      if (c == 0) k.g_w[rdst] = wsum;
+      if (adam) {
+        const int64_t rid = k.col_uid[(int64_t)f * B + ru];
+        if ((uint64_t)rid < (uint64_t)k.V) {
+          adam_chunk(k, rid, c, h);
+          if (c == 0) adam_w(k, rid, wsum);
+        }
+      }
     }
   }
   if (bidx == 0 && tid == 0) *k.n_uniq = total;
@@ -1162,7 +1209,8 @@ extern "C" int rec_deepfm_fused_step_f32(const float* table, int64_t ld, int64_t
   if ((reinterpret_cast<uintptr_t>(vals) & 15) != 0 || (reinterpret_cast<uintptr_t>(g_embed_rows) & 15) != 0)
     return REC_E_UNSUPPORTED;
   ColSegArgs k{(const float4*)vals, gz, perm, col_uid, col_seg, col_nu, B, F, uniq_ids, (float4*)g_embed_rows,
-               packed ? (float*)nullptr : g_w_rows, n_uniq, packed ? 1 : 0};
+               packed ? (float*)nullptr : g_w_rows, n_uniq, packed ? 1 : 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f,
+               0.f, 0.f, 0.f};
   return launch_fused(table, ld, V, cols_host, F, B, bias, K0, b0, K1, b1, K2, b2, label, gz, vals, prob, dK0, db0, dK1,
                       db1, dK2, db2, dbias, loss, oob_flag, workspace, stream, &k);
 }
@@ -1184,7 +1232,7 @@ static int launch_post(bool direct, int F, int64_t B, const float* gz, const flo
                        float* dK1, float* db1, float* dK2, float* db2, float* dbias, float* loss, void* workspace,
                        const int32_t* perm, const int64_t* col_uid, const int32_t* col_seg, const int32_t* col_nu,
                        int64_t* uniq_ids, float* g_embed_rows, float* g_w_rows, int64_t* n_uniq, int packed,
-                       void* stream) {
+                       void* stream, const ColSegArgs* adam = nullptr) {
   if (B <= 0 || F <= 0 || F > 28) return REC_E_ARG;
   if (!gz || !vals || !dK0 || !db0 || !dK1 || !db1 || !dK2 || !db2 || !dbias || !loss || !workspace || !perm ||
       !col_uid || !col_seg || !col_nu || !uniq_ids || !g_embed_rows || !n_uniq || (!packed && !g_w_rows))
@@ -1200,7 +1248,12 @@ static int launch_post(bool direct, int F, int64_t B, const float* gz, const flo
   unsigned nbs = (unsigned)ceil_div64(B * F * 4, 1024);
   ReduceArgs r{dK0part, small, nwg, D, B, dK0, dK1, db0, db1, dK2, db2, dbias, loss};
   ColSegArgs k{(const float4*)vals, gz, perm, col_uid, col_seg, col_nu, B, F, uniq_ids, (float4*)g_embed_rows,
-               packed ? (float*)nullptr : g_w_rows, n_uniq, packed ? 1 : 0};
+               packed ? (float*)nullptr : g_w_rows, n_uniq, packed ? 1 : 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f,
+               0.f, 0.f, 0.f};
+  if (adam) {
+    k.table = adam->table; k.m_e = adam->m_e; k.v_e = adam->v_e; k.m_w = adam->m_w; k.v_w = adam->v_w; k.V = adam->V;
+    k.lr_t = adam->lr_t; k.b1 = adam->b1; k.b2 = adam->b2; k.eps = adam->eps;
+  }
   if (direct) {
     unsigned nbf = (unsigned)F * (unsigned)ceil_div64(B, FIX_T);
     hipLaunchKernelGGL(deepfm_post_direct_kernel, dim3(nb + nbf), dim3(1024), 0, as_stream(stream), r, k, (int)nb);
@@ -1247,6 +1300,31 @@ extern "C" int rec_deepfm_fused_post_direct_f32(int F, int64_t B, const float* g
                                                 float* g_embed_rows, float* g_w_rows, int64_t* n_uniq, void* stream) {
   return launch_post(true, F, B, gz, vals, dK0, db0, dK1, db1, dK2, db2, dbias, loss, workspace, perm, col_uid, col_seg,
                      col_nu, uniq_ids, g_embed_rows, g_w_rows, n_uniq, 0, stream);
+}
+
+// ... with the lazy (touched-rows) Adam update of both tables (rec_adam_rows_f32's arithmetic) applied to every row the
+// moment its gradient is final: no second pass over g_embed_rows / g_w_rows, no extra launch.  table: the fused rows
+// [V, 32] (embed 16 | w | pad); t: 1-based step for the bias correction.  Non-reference semantics (Keras' sparse apply is
+// a dense sweep: rec_adam_sparse_keras_pair_f32), opt-in.
+extern "C" int rec_deepfm_fused_post_direct_adam_f32(int F, int64_t B, const float* gz, const float* vals, float* dK0,
+                                                     float* db0, float* dK1, float* db1, float* dK2, float* db2,
+                                                     float* dbias, float* loss, void* workspace, const int32_t* perm,
+                                                     const int64_t* col_uid, const int32_t* col_seg,
+                                                     const int32_t* col_nu, int64_t* uniq_ids, float* g_embed_rows,
+                                                     float* g_w_rows, int64_t* n_uniq, float* table, int64_t ld,
+                                                     int64_t V, float* m_e, float* v_e, float* m_w, float* v_w, int64_t t,
+                                                     float lr, float b1, float b2, float eps, void* stream) {
+  if (!table || !m_e || !v_e || !m_w || !v_w || V <= 0 || t < 1) return REC_E_ARG;
+  if (ld != LD || (reinterpret_cast<uintptr_t>(table) & 15) != 0 || (reinterpret_cast<uintptr_t>(m_e) & 15) != 0 ||
+      (reinterpret_cast<uintptr_t>(v_e) & 15) != 0)
+    return REC_E_UNSUPPORTED;
+  // float32 arithmetic as Keras does (tf.pow on float32 scalars), the same as rec_adam_rows_f32
+  const float b1p = powf(b1, (float)t), b2p = powf(b2, (float)t);
+  ColSegArgs a{};
+  a.table = table; a.m_e = m_e; a.v_e = v_e; a.m_w = m_w; a.v_w = v_w; a.V = V;
+  a.lr_t = lr * sqrtf(1.f - b2p) / (1.f - b1p); a.b1 = b1; a.b2 = b2; a.eps = eps;
+  return launch_post(true, F, B, gz, vals, dK0, db0, dK1, db1, dK2, db2, dbias, loss, workspace, perm, col_uid, col_seg,
+                     col_nu, uniq_ids, g_embed_rows, g_w_rows, n_uniq, 0, stream, &a);
 }
 
 extern "C" size_t rec_colsort_workspace_bytes(int64_t B, int F) {
@@ -1316,7 +1394,7 @@ extern "C" int rec_colseg_sum_f32(const float* vals, const float* gz, const int3
     return REC_E_UNSUPPORTED;
   int64_t groups = B * F;
   ColSegArgs k{(const float4*)vals, gz, perm, col_uid, col_seg, col_nu, B, F, uniq_ids, (float4*)g_embed_rows,
-               g_w_rows, n_uniq, 0};
+               g_w_rows, n_uniq, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0.f, 0.f};
   hipLaunchKernelGGL(colseg_sum_kernel, dim3((unsigned)ceil_div64(groups * 4, 256)), dim3(256), 0, as_stream(stream), k);
   REC_LAUNCH_CHECK();
   return REC_OK;
@@ -1331,7 +1409,7 @@ extern "C" int rec_colseg_sum_packed_f32(const float* vals, const float* gz, con
     return REC_E_UNSUPPORTED;
   int64_t groups = B * F;
   ColSegArgs k{(const float4*)vals, gz, perm, col_uid, col_seg, col_nu, B, F, uniq_ids, (float4*)g_rows,
-               (float*)nullptr, n_uniq, 1};
+               (float*)nullptr, n_uniq, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0.f, 0.f};
   hipLaunchKernelGGL(colseg_sum_kernel, dim3((unsigned)ceil_div64(groups * 4, 256)), dim3(256), 0, as_stream(stream), k);
   REC_LAUNCH_CHECK();
   return REC_OK;

@@ -377,10 +377,26 @@ class DeepFMFusedStep:
             _p(L.MLP_layer2.bias_0), _p(label), _p(self.gz), _p(self.vals), None, _p(self.oob), _p(self.ws),
             _p(pl["dloc"]), _p(pl["col_nu"]), _p(self.g_embed_rows), st), "rec_deepfm_fused_main_direct_f32")
 
-    def _launch_post(self, buf, st):
+    def _fused_lazy(self):
+        """optimizer 'lazy_adam' in direct mode: the touched-rows Adam of both tables rides in the post launch"""
+        return self.optimizer == "lazy_adam" and self.direct
+
+    def _launch_post(self, buf, st, t=0):
         """reduction of the workgroup partials side by side with the segment sums (direct mode: with what is left of
         them -- runs of more than one lookup and the padded tail) in ONE launch"""
         g, pl = self.g, self.plans[buf]
+        if self._fused_lazy():
+            params = dict(self.layer.named_parameters())
+            pe = params["embed.embeddings"]
+            (me, ve), (mw, vw) = self.state["embed.embeddings"], self.state["w.embeddings"]
+            check(lib.rec_deepfm_fused_post_direct_adam_f32(
+                self.F, self.B, _p(self.gz), _p(self.vals), _p(g["MLP_layer1.kernel_0"]), _p(g["MLP_layer1.bias_0"]),
+                _p(g["MLP_layer1.kernel_1"]), _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]),
+                _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(self.loss), _p(self.ws), _p(pl["perm"]),
+                _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.uniq_ids), _p(self.g_embed_rows),
+                _p(self.g_w_rows), _p(self.n_uniq), _p(pe), pe.stride(0), self.V, _p(me), _p(ve), _p(mw), _p(vw), t,
+                self.lr, 0.9, 0.999, 1e-7, st), "rec_deepfm_fused_post_direct_adam_f32")
+            return
         if not self.direct:
             check(lib.rec_deepfm_fused_post_f32(
                 self.F, self.B, _p(self.gz), _p(self.vals), _p(g["MLP_layer1.kernel_0"]), _p(g["MLP_layer1.bias_0"]),
@@ -405,6 +421,8 @@ class DeepFMFusedStep:
                   "rec_adam_dense_f32")
         n = self.B * self.F
         pe, pw = params["embed.embeddings"], params["w.embeddings"]
+        if self._fused_lazy():
+            return                                               # the tables were updated inside the post launch
         if self.optimizer == "keras_adam" and _tables_share_rows(pe, pw):
             # one sweep over the fused [embed | w | pad] rows instead of one per table
             (me, ve), (mw, vw) = self.state["embed.embeddings"], self.state["w.embeddings"]
@@ -505,9 +523,10 @@ class DeepFMFusedStep:
             for i in range(n):
                 if i > 0:
                     self._launch_main(seq[i][0], seq[i][1], st, bufs[i])
-                self._launch_post(bufs[i], st)
                 if self.optimizer is not None:
                     self.t += 1
+                self._launch_post(bufs[i], st, self.t)
+                if self.optimizer is not None:
                     self._optimizer(self.t, st)
             if then_cols:
                 main.wait_stream(side)                           # join: the next call relies on the other half

@@ -287,6 +287,17 @@ int rec_deepfm_fused_post_direct_f32(int F, int64_t B, const float* gz, const fl
                                      void* workspace, const int32_t* perm, const int64_t* col_uid, const int32_t* col_seg,
                                      const int32_t* col_nu, int64_t* uniq_ids, float* g_embed_rows, float* g_w_rows,
                                      int64_t* n_uniq, void* stream);
+/* rec_deepfm_fused_post_direct_f32 + the lazy (touched-rows) Adam update of both tables applied to each row the moment its
+ * gradient is final (optimizer in the backward; arithmetic of rec_adam_rows_f32; NOT Keras' dense-sweep
+ * semantics of 2.FM/ModelManager.py:104,178-179 -- opt-in).  table: fused rows [V,32] = [embed 16 | w | pad] (ld = 32);
+ * m_e, v_e [V,16]; m_w, v_w [V]; t: 1-based step. */
+int rec_deepfm_fused_post_direct_adam_f32(int F, int64_t B, const float* gz, const float* vals, float* dK0, float* db0,
+                                          float* dK1, float* db1, float* dK2, float* db2, float* dbias, float* loss,
+                                          void* workspace, const int32_t* perm, const int64_t* col_uid,
+                                          const int32_t* col_seg, const int32_t* col_nu, int64_t* uniq_ids,
+                                          float* g_embed_rows, float* g_w_rows, int64_t* n_uniq, float* table, int64_t ld,
+                                          int64_t V, float* m_e, float* v_e, float* m_w, float* v_w, int64_t t, float lr,
+                                          float b1, float b2, float eps, void* stream);
 /* segment sums of vals [B*F,16] (embed) and gz [B] (w) over that plan + compaction to the global ascending list:
  * uniq_ids [B*F], g_embed_rows [B*F,16], g_w_rows [B*F], n_uniq; the tail is padded like rec_dedup_plan_i64's. */
 int rec_colseg_sum_f32(const float* vals, const float* gz, const int32_t* perm, const int64_t* col_uid,

@@ -306,6 +306,45 @@ def test_fused_step_with_keras_adam_matches_generic():
         assert np.abs(p.detach().cpu().numpy() - q.detach().cpu().numpy()).max() <= 2e-5, k
 
 
+@pytest.mark.parametrize("dist", ["uniform", "zipf"])
+def test_fused_step_lazy_adam_in_post_launch(dist):
+    """the touched-rows Adam of both tables applied INSIDE the post launch (direct mode) against (a) the
+    same update as separate launches over the finished row gradients (rec_adam_rows_f32: same arithmetic) and (b) the oracle's lazy Adam (L.adam_rows_step) on the oracle's own gradients, three steps."""
+    from explicit_tf2_recommendation_amd import engine, data
+    B, F, V = 2048, 26, 40000
+    la, names, gen = make16(B, F, V, 31, dist)
+    lb, _, _ = make16(B, F, V, 31, dist)
+    lb.load_state_dict(la.state_dict())
+    a = engine.DeepFMFusedStep(la, B, gen.dims, gen.offsets, optimizer="lazy_adam", lr=0.01, use_graph=False)
+    b = engine.DeepFMFusedStep(lb, B, gen.dims, gen.offsets, optimizer="lazy_adam", lr=0.01, use_graph=False,
+                               direct=False)              # classic path: rows updated by rec_adam_rows_f32 afterwards
+    assert a._fused_lazy() and not b._fused_lazy()
+    emb = la.embed.embeddings.detach().cpu().numpy().copy()
+    w = la.w.embeddings.detach().cpu().numpy().copy()
+    st = {"e": (emb.copy(), np.zeros_like(emb), np.zeros_like(emb)), "w": (w.copy(), np.zeros_like(w), np.zeros_like(w))}
+    for t in range(1, 4):
+        host = gen.batch(B)
+        # oracle gradients at the CURRENT parameters of `a`, then the oracle's lazy Adam
+        _, ref = oracle_grads(la, names, host)
+        touched = np.unique(L.index_assemble(host, names))
+        st["e"] = L.adam_rows_step(st["e"][0], st["e"][1], st["e"][2], touched, ref["embed.embeddings"][touched]
+                                   .astype(np.float32), t, lr=0.01, dt=np.float32)
+        st["w"] = L.adam_rows_step(st["w"][0], st["w"][1], st["w"][2], touched, ref["w.embeddings"][touched]
+                                   .astype(np.float32), t, lr=0.01, dt=np.float32)
+        batch = data.to_device(host)
+        a(batch)
+        b(batch)
+        a.check_flags()
+        # same formula in two kernels: the compiler contracts m*b1 + g*(1-b1) into an fma its own way in each, and
+        # runs of more than 8 lookups are summed in another (fixed) order -- equal to rounding, not bit for bit
+        for (k, p), (_, q) in zip(la.named_parameters(), lb.named_parameters()):
+            assert (p - q).abs().max().item() <= 1e-6, (t, k)
+        assert np.abs(la.embed.embeddings.detach().cpu().numpy() - st["e"][0]).max() <= 2e-5, t
+        assert np.abs(la.w.embeddings.detach().cpu().numpy() - st["w"][0]).max() <= 2e-5, t
+    assert (a.state["embed.embeddings"][0] - b.state["embed.embeddings"][0]).abs().max().item() <= 1e-6
+    assert (a.state["w.embeddings"][1] - b.state["w.embeddings"][1]).abs().max().item() <= 1e-6
+
+
 @pytest.mark.parametrize("family", ["dssm", "dcn_matrix", "dcn_vec", "din"])
 def test_graphed_train_step_equals_eager_autograd(family):
     """engine.GraphedTrainStep: forward + KerasBCE + autograd backward replayed from one hipGraph must give the eager
