@@ -110,6 +110,22 @@ def _load():
 
 lib = _load()
 
+# The hot operators are also registered with the PyTorch dispatcher -- TORCH_LIBRARY(mi355rec, ...) in csrc/torch_ops.cpp,
+# a host-only wrapper over the SAME C ABI -- and ops.py calls them as torch.ops.mi355rec.<op>: one dispatcher hop per
+# operator instead of a ctypes call with ~20 marshalled arguments.  Part of the product: missing -> ImportError.
+TORCH_LIB_PATH = os.path.join(_HERE, "csrc", "libmi355rec_torch.so")
+
+
+def _load_torch_ops():
+    import torch
+    if not os.path.exists(TORCH_LIB_PATH):
+        raise ImportError("%s not found: build it with __graft_entry__.build() or csrc/build.sh" % TORCH_LIB_PATH)
+    torch.ops.load_library(TORCH_LIB_PATH)
+    return torch.ops.mi355rec
+
+
+tops = _load_torch_ops()
+
 
 class RecError(RuntimeError):
     pass

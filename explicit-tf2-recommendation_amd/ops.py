@@ -8,7 +8,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import lib, check
+from ._lib import lib, check, tops
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_SIGMOID, EPI_BIAS_TANH, EPI_CROSS, EPI_ADD = range(7)
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = range(4)
@@ -73,11 +73,7 @@ def index_pack(cols, out=None, col0=0):
         _i64(c, "index column")
         if c.numel() != rows:
             raise ValueError("index columns differ in length")
-    if out is None:
-        out = torch.empty((rows, F), dtype=torch.int64, device=cols[0].device)
-    arr = (C.c_void_p * F)(*[c.data_ptr() for c in cols])
-    check(lib.rec_index_pack_i64(arr, F, rows, _ptr(out), out.shape[1], col0, _stream()), "rec_index_pack_i64")
-    return out
+    return tops.index_pack(list(cols), out, col0)
 
 
 def new_flag(device):
@@ -86,39 +82,19 @@ def new_flag(device):
 
 def emb_gather(table, idx, oob=None):
     _table(table, "table"); _i64(idx, "idx")
-    V, E = table.shape
-    out = torch.empty(tuple(idx.shape) + (E,), dtype=torch.float32, device=table.device)
-    check(lib.rec_emb_gather_f32(_ptr(table), V, E, table.stride(0), _ptr(idx), idx.numel(), _ptr(out), _ptr(oob),
-                                 _stream()), "rec_emb_gather_f32")
-    return out
+    return tops.emb_gather(table, idx, oob)
 
 
 def emb_fm_fwd(embed, w, bias, X, want_prob=False, want_rows=False, want_sum=True, oob=None):
     """Fused w(X), embed(X) and the FM sum-square trick.  Returns z [B], prob [B]|None, rows [B,F,E]|None,
     sumvec [B,E]|None."""
     _table(embed, "embed"); _table(w, "w"); _f32(bias, "bias"); _i64(X, "X")
-    V, E = embed.shape
-    B, F = X.shape
-    dev = embed.device
-    z = torch.empty(B, dtype=torch.float32, device=dev)
-    prob = torch.empty(B, dtype=torch.float32, device=dev) if want_prob else None
-    rows = torch.empty((B, F, E), dtype=torch.float32, device=dev) if want_rows else None
-    S = torch.empty((B, E), dtype=torch.float32, device=dev) if want_sum else None
-    check(lib.rec_emb_fm_fwd_f32(_ptr(embed), embed.stride(0), _ptr(w), w.stride(0), _ptr(bias), V, E, _ptr(X), B, F,
-                                 _ptr(z), _ptr(prob), _ptr(rows), _ptr(S), _ptr(oob), _stream()),
-          "rec_emb_fm_fwd_f32")
-    return z, prob, rows, S
+    return tops.emb_fm_fwd(embed, w, bias, X, want_prob, want_rows, want_sum, oob)
 
 
 def emb_fm_bwd_vals(embed, X, gz, sumvec, rows=None, extra=None):
     """IndexedSlices values of the FM part: [B*F, E]."""
-    V, E = embed.shape
-    B, F = X.shape
-    out = torch.empty((B * F, E), dtype=torch.float32, device=embed.device)
-    check(lib.rec_emb_fm_bwd_vals_f32(_ptr(embed), embed.stride(0), V, E, _ptr(X), B, F, _ptr(_f32(gz, "gz")),
-                                      _ptr(sumvec), _ptr(rows), _ptr(extra), _ptr(out), _stream()),
-          "rec_emb_fm_bwd_vals_f32")
-    return out
+    return tops.emb_fm_bwd_vals(embed, X, _f32(gz, "gz"), sumvec, rows, extra)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -137,16 +113,15 @@ class DedupPlan:
         n = ids.numel()
         dev = ids.device
         self.n = n
-        self.uniq_ids = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
-        self.seg_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
-        self.perm = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-        self.n_uniq = torch.empty(1, dtype=torch.int64, device=dev)
-        nbytes = lib.rec_dedup_workspace_bytes(n)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         if list_counts is None:
-            check(lib.rec_dedup_plan_i64(_ptr(ids), n, V, _ptr(self.uniq_ids), _ptr(self.seg_start), _ptr(self.perm),
-                                         _ptr(self.n_uniq), _ptr(ws), nbytes, _stream()), "rec_dedup_plan_i64")
+            self.uniq_ids, self.seg_start, self.perm, self.n_uniq = tops.dedup_plan(ids, V)
         else:
+            self.uniq_ids = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+            self.seg_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+            self.perm = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+            self.n_uniq = torch.empty(1, dtype=torch.int64, device=dev)
+            nbytes = lib.rec_dedup_workspace_bytes(n)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             lc = _i64(list_counts.reshape(-1), "list_counts")
             check(lib.rec_dedup_plan_sorted_lists_i64(_ptr(ids), n, _ptr(lc), lc.numel(), V, _ptr(self.uniq_ids),
                                                       _ptr(self.seg_start), _ptr(self.perm), _ptr(self.n_uniq),
@@ -161,11 +136,7 @@ class DedupPlan:
                 c1 = min(E, c0 + 256)
                 out[:, c0:c1] = self.segment_sum(vals[:, c0:c1].contiguous(), c1 - c0, row_div)
             return out
-        out = torch.empty((max(self.n, 1), E), dtype=torch.float32, device=vals.device)
-        ws = torch.empty(lib.rec_segment_sum_workspace_bytes(self.n, E) // 4, dtype=torch.float32, device=vals.device)
-        check(lib.rec_segment_sum_f32(_ptr(_f32(vals, "vals")), E, _ptr(self.perm), _ptr(self.seg_start), self.n,
-                                      row_div, _ptr(out), _ptr(ws), _stream()), "rec_segment_sum_f32")
-        return out
+        return tops.segment_sum(_f32(vals, "vals"), E, self.perm, self.seg_start, self.n, row_div)
 
 
 def l2_used_rows(table, plan, factor):
@@ -213,50 +184,29 @@ def gemm(A, B, transA=False, transB=False, epi=EPI_NONE, bias=None, e0=None, e1=
     if split_k is None:
         skinny = (not transA) and (not transB) and N <= 64 and M >= 256      # the no-LDS kernel splits K over its waves
         split_k = 1 if skinny else split_k_for(K, M, N, transA, transB)
-    ws = None
-    if split_k > 1:
-        ws = torch.empty((split_k, M, N), dtype=torch.float32, device=A.device)
-    check(lib.rec_gemm_f32(int(transA), int(transB), M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out),
-                           out.stride(0), epi, _ptr(bias), _ptr(e0), e0.stride(0) if e0 is not None else 0,
-                           _ptr(e1), e1.stride(0) if e1 is not None else 0, split_k, _ptr(ws), _ptr(aux), _stream()),
-          "rec_gemm_f32")
-    return out
+    return tops.gemm(A, B, bool(transA), bool(transB), epi, bias, e0, e1, int(split_k), out, aux)
 
 
 def act_fwd(act, x, x2=None):
     """y = act(x + x2)."""
-    y = torch.empty_like(x)
-    check(lib.rec_act_fwd_f32(act, _ptr(_f32(x, "x")), _ptr(x2), _ptr(y), x.numel(), _stream()), "rec_act_fwd_f32")
-    return y
+    return tops.act_fwd(act, _f32(x, "x"), x2)
 
 
 def crossnet_mat_bwd_elem(g, x0, u, gx0, accumulate):
     """h = g*x0 (returned); gx0 (+)= g*u in place."""
-    h = torch.empty_like(g)
-    check(lib.rec_crossnet_mat_bwd_elem_f32(_ptr(_f32(g, "g")), _ptr(x0), _ptr(u), _ptr(h), _ptr(gx0),
-                                            int(accumulate), g.numel(), _stream()), "rec_crossnet_mat_bwd_elem_f32")
-    return h
+    return tops.crossnet_mat_bwd_elem(_f32(g, "g"), x0, u, gx0, bool(accumulate))
 
 
 def act_bwd(act, post, dpost):
-    out = torch.empty_like(dpost)
-    check(lib.rec_act_bwd_f32(act, _ptr(_f32(post, "post")), _ptr(_f32(dpost, "dpost")), _ptr(out), post.numel(),
-                              _stream()), "rec_act_bwd_f32")
-    return out
+    return tops.act_bwd(act, _f32(post, "post"), _f32(dpost, "dpost"))
 
 
 def colsum(X, out=None):
-    M, N = X.shape
-    if out is None:
-        out = torch.empty(N, dtype=torch.float32, device=X.device)
-    ws = torch.empty(lib.rec_colsum_workspace_bytes(M, N) // 4, dtype=torch.float32, device=X.device)
-    check(lib.rec_colsum_f32(_ptr(X), M, N, X.stride(0), _ptr(out), _ptr(ws), _stream()), "rec_colsum_f32")
-    return out
+    return tops.colsum(X, out)
 
 
 def axpby(a, x, b, y):
-    check(lib.rec_axpby_f32(a, _ptr(_f32(x, "x")), b, _ptr(_f32(y, "y")), x.numel(), _stream()), "rec_axpby_f32")
-    return y
+    return tops.axpby(float(a), _f32(x, "x"), float(b), _f32(y, "y"))
 
 
 def copy_cols(src, dst_view):
@@ -308,31 +258,17 @@ def crossnet_vec_bwd(x0, w, xs, gy):
 
 
 def cosine_fwd(u, i):
-    B, d = u.shape
-    out = torch.empty(B, dtype=torch.float32, device=u.device)
-    check(lib.rec_cosine_fwd_f32(_ptr(_f32(u, "u")), _ptr(_f32(i, "i")), B, d, _ptr(out), _stream()),
-          "rec_cosine_fwd_f32")
-    return out
+    return tops.cosine_fwd(_f32(u, "u"), _f32(i, "i"))
 
 
 def cosine_bwd(u, i, gout):
-    B, d = u.shape
-    gu, gi = torch.empty_like(u), torch.empty_like(i)
-    check(lib.rec_cosine_bwd_f32(_ptr(u), _ptr(i), B, d, _ptr(_f32(gout, "gout")), _ptr(gu), _ptr(gi), _stream()),
-          "rec_cosine_bwd_f32")
-    return gu, gi
+    return tops.cosine_bwd(u, i, _f32(gout, "gout"))
 
 
 def bce_fwd_bwd(y, p, want_dp=True, want_dz=False):
     y = _f32(y.reshape(-1), "y")
     p = _f32(p.reshape(-1), "p")
-    n = p.numel()
-    loss = torch.empty(1, dtype=torch.float32, device=p.device)
-    dp = torch.empty(n, dtype=torch.float32, device=p.device) if want_dp else None
-    dz = torch.empty(n, dtype=torch.float32, device=p.device) if want_dz else None
-    check(lib.rec_bce_fwd_bwd_f32(_ptr(y), _ptr(p), n, _ptr(loss), _ptr(dp), _ptr(dz), _stream()),
-          "rec_bce_fwd_bwd_f32")
-    return loss, dp, dz
+    return tops.bce_fwd_bwd(y, p, bool(want_dp), bool(want_dz))
 
 
 def adam_dense(var, m, v, g, t, lr, b1=0.9, b2=0.999, eps=1e-7):

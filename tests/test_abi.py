@@ -113,3 +113,21 @@ def test_synthetic_generator_honours_the_datagenerator_contract():
     a = data.SyntheticGenerator(names, V, seed=5).batch(10)
     c = data.SyntheticGenerator(names, V, seed=5).batch(10)
     assert all(np.array_equal(a[k], c[k]) for k in a)   # seeded
+
+
+def test_torch_library_registration():
+    """the hot operators are registered with the PyTorch dispatcher as TORCH_LIBRARY(mi355rec, ...)
+    (csrc/torch_ops.cpp, a host-only wrapper over the same C ABI); ops.py calls them as torch.ops.mi355rec.<op>."""
+    import torch
+    from explicit_tf2_recommendation_amd import _lib, ops  # noqa: F401  (importing the package loads the library)
+    assert os.path.exists(_lib.TORCH_LIB_PATH)
+    names = ["index_pack", "emb_gather", "emb_fm_fwd", "emb_fm_bwd_vals", "gemm", "act_fwd", "act_bwd", "colsum",
+             "bce_fwd_bwd", "dedup_plan", "segment_sum", "cosine_fwd", "cosine_bwd", "crossnet_mat_bwd_elem", "axpby"]
+    for n in names:
+        op = getattr(torch.ops.mi355rec, n)
+        assert "mi355rec::" + n in str(op.default._schema)
+    assert "Tensor A, Tensor B, bool transA, bool transB" in str(torch.ops.mi355rec.gemm.default._schema)
+    # no CPU kernel is registered: the dispatcher refuses CPU tensors (the HIP path has no fallback)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.mi355rec.cosine_fwd(torch.zeros(2, 4), torch.zeros(2, 4))
+
