@@ -2,27 +2,26 @@
 // default head (embedding_dims = 16, mlp_dims = [32, 8]) on the fused [embed(16) | w | pad] 128-byte row layout.
 //
 // The generic path runs ~35 launch-bound kernels per step (profiles/r01_v1_*): at batch 8192 every small kernel costs
-// ~5 us while the whole gather is ~4 us of HBM time.  Here a step is two launches on the main stream plus the sort of an
-// upcoming batch's ids on a second one:
+// ~5 us while the whole gather is ~4 us of HBM time.  Here a step is two launches on the main stream plus the sort of
+// upcoming batches' ids on a second one:
 //
-//   deepfm_fwd_bwd_kernel   one workgroup (4 waves) per 32 examples: index assembly straight from the F feature
-//                           columns, gather of the 128-B rows (26 independent 16-B loads in flight per lane), FM,
-//                           MLP 416->32 on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, operands from LDS, K split
-//                           over the waves), the two small layers + sigmoid + Keras BCE + their backward on the VALU,
-//                           dX = dpre1 . K0^T and the per-workgroup dK0 partial on the matrix cores (one 32-wide tile
-//                           per wave at a time), and the IndexedSlices values dz*(S - e) + dX written once as full
-//                           128-byte lines.  The embedding rows never leave LDS.
-//   deepfm_post_kernel      ONE launch, two jobs side by side: the fixed-order sum of the per-workgroup partials (dK0,
-//                           dK1, biases, loss) and the segment sums of embed and w gradients over the batch's
-//                           de-duplication plan + global compaction (column counts prefix).  (deepfm_reduce_kernel
-//                           and colseg_sum_kernel are the same two jobs as separate launches.)
-//   colsort_*_kernel (3)    de-duplication plan: the DataGenerator contract (2.FM/DataGenerator.py:76-88) gives every
+//   deepfm_fwd_bwd_kernel   one 8-wave workgroup per 32 examples; wave w owns fields w, w+8, ... from the id load to
+//                           the last store: gather of the 128-B rows, layer 1 (416->32) on v_mfma_f32_32x32x2_f32
+//                           UNDER the gather, the 32->8->1 head + sigmoid + Keras BCE + the way back inside 16-lane
+//                           groups (DPP reductions), dX = dpre1 . K0^T and the workgroup's dK0 partial on
+//                           v_mfma_f32_16x16x4_f32 tiles per field.  Direct mode: the IndexedSlices value row of a
+//                           lookup that heads its run of equal ids goes straight to the run's slot of the
+//                           de-duplicated gradient (the plan exists before the launch).  Details above the kernel.
+//   deepfm_post_direct_kernel  ONE launch, two jobs side by side: the fixed-order sum of the per-workgroup partials
+//                           (dK0, dK1, biases, loss) over ~210 workgroups, and what is left of the segment sums --
+//                           runs of more than one lookup, unique ids, first-order rows, zero-padded tail; optionally
+//                           the lazy Adam update of every finished row.  (deepfm_post_kernel / deepfm_reduce_kernel /
+//                           colseg_sum_kernel: the plain, non-direct forms used by the row-sharded step.)
+//   colsort_onewg_kernel    de-duplication plan: the DataGenerator contract (2.FM/DataGenerator.py:76-88) gives every
 //                           feature column its own contiguous id range, so duplicates only occur inside a column:
-//                           each column (B <= 16384 ids) is sorted on its own as 32-bit (key << PB | position) words
-//                           -- 1024-id chunks by a bitonic network (registers / wave shuffles / LDS), chunks merged
-//                           by ranking (binary searches in LDS), then run detection, all on a (B/1024) x columns
-//                           grid.  Depends on ids only: the engine runs it ahead, on a second stream, for up to two
-//                           upcoming batches per call.
+//                           one 1024-thread workgroup sorts a column (B <= 16384 ids) in LDS as 32-bit
+//                           (key << PB | position) words and finds the runs.  Depends on ids only: the engine runs it
+//                           ahead, on a second stream, for the batches of the next call (up to 4 per launch).
 //
 // Everything is deterministic (no float atomics): per-workgroup partials + fixed-order reductions, stable sort keys.
 #include "common.h"
@@ -97,22 +96,19 @@ __device__ __forceinline__ int xs_of(int F) { return F * E16 + 4; }
 
 // LDS carve (floats); everything in ONE dynamic array
 struct Carve {
-  int XT, PT, SP, SQ, WP, H1s, DP1, Ss, h2s, dp2s, zfm, dzs, lss, K1s, b0s, b1s, K2s, total;
+  int XT, PT, WP, H1s, DP1, Ss, h2s, dp2s, dzs, lss, K1s, b0s, b1s, K2s, total;
 };
 __host__ __device__ inline Carve carve_of(int F) {
   Carve c;
   int o = 0;
   c.XT = o; o += EX * (F * E16 + 4);
   c.PT = o; o += NWV * EX * HSP;
-  c.SP = o; o += NWV * EX * E16;
-  c.SQ = o; o += NWV * EX * 2;
   c.WP = o; o += NWV * EX;
   c.H1s = o; o += EX * HS1;
   c.DP1 = o; o += EX * HS1;
   c.Ss = o; o += EX * E16;
   c.h2s = o; o += EX * U2;
   c.dp2s = o; o += EX * U2;
-  c.zfm = o; o += EX;
   c.dzs = o; o += EX;
   c.lss = o; o += EX;
   c.K1s = o; o += U1 * U2;
@@ -145,15 +141,12 @@ __global__ __launch_bounds__(512) void deepfm_fwd_bwd_kernel(Cols cols, FusedArg
   const Carve cv = carve_of(F);
   float* XT = lds + cv.XT;               // [EX][XS]
   float* PT = lds + cv.PT;               // [8][EX][HSP]   partial layer-1 tiles
-  float* SP = lds + cv.SP;               // [8][EX][16]    partial sums of e over the wave's fields
-  float* SQ = lds + cv.SQ;               // [8][EX][2]     partial sums of e^2 (lane halves)
   float* WP = lds + cv.WP;               // [8][EX]        partial first-order sums
   float* H1s = lds + cv.H1s;             // [EX][HS1]      relu(h1)
   float* DP1 = lds + cv.DP1;             // [EX][HS1]      d pre-activation of layer 1
   float* Ss = lds + cv.Ss;               // [EX][16]
   float* h2s = lds + cv.h2s;             // [EX][8]
   float* dp2s = lds + cv.dp2s;           // [EX][8]
-  float* zfm = lds + cv.zfm;
   float* dzs = lds + cv.dzs;
   float* lss = lds + cv.lss;
   float* K1s = lds + cv.K1s;             // [32][8]
@@ -237,9 +230,7 @@ __global__ __launch_bounds__(512) void deepfm_fwd_bwd_kernel(Cols cols, FusedArg
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float sx[8], sq = 0.f, wacc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) sx[j] = 0.f;
+    float wacc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < MAXFW; ++i) {
       const int f = wave + NWV * i;
@@ -256,20 +247,12 @@ __global__ __launch_bounds__(512) void deepfm_fwd_bwd_kernel(Cols cols, FusedArg
         const float4 x1 = *reinterpret_cast<const float4*>(XT + lo * XS + f * E16 + 8 * hi + 4);
         const float xa[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          sx[s] += xa[s];
-          sq += xa[s] * xa[s];
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s], kb[i][s], acc, 0, 0, 0);
-        }
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s], kb[i][s], acc, 0, 0, 0);
       }
     }
     float* pt = PT + wave * (EX * HSP);
 #pragma unroll
     for (int r = 0; r < 16; ++r) pt[((r & 3) + 8 * (r >> 2) + 4 * hi) * HSP + lo] = acc[r];
-    float* sp = SP + (wave * EX + lo) * E16 + 8 * hi;
-    *reinterpret_cast<float4*>(sp) = make_float4(sx[0], sx[1], sx[2], sx[3]);
-    *reinterpret_cast<float4*>(sp + 4) = make_float4(sx[4], sx[5], sx[6], sx[7]);
-    SQ[(wave * EX + lo) * 2 + hi] = sq;
     if (c == 4) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) WP[wave * EX + 8 * g + ep] = wacc[g];
@@ -326,12 +309,20 @@ __global__ __launch_bounds__(512) void deepfm_fwd_bwd_kernel(Cols cols, FusedArg
     const float h1a = fmaxf(h.x + b0s[2 * g16], 0.f), h1b = fmaxf(h.y + b0s[2 * g16 + 1], 0.f);
     H1s[e16 * HS1 + 2 * g16] = h1a;                       // kept for the dK1 partial of phase C
     H1s[e16 * HS1 + 2 * g16 + 1] = h1b;
-    // FM: S_d (lane = dim), sum of squares and first order (one partial per lane), reduced over the 16 lanes
-    float sd = 0.f;
-#pragma unroll
-    for (int w = 0; w < NWV; ++w) sd += SP[(w * EX + e16) * E16 + g16];
+    // FM: lane = dim d of the example: S_d and the sum of squares of that dim over the fields, straight from the rows
+    // in LDS (the per-wave partial sums of round 2's first version cost 18 KB of LDS: with them the 37-KB sort workgroup
+    // of the second stream could not share the CU and delayed every fused kernel it overlapped by a whole round)
+    float sd = 0.f, sqd = 0.f;
+    {
+      const float* xr = XT + e16 * XS + g16;
+      for (int f = 0; f < F; ++f) {
+        const float x = xr[f * E16];
+        sd += x;
+        sqd += x * x;
+      }
+    }
     Ss[e16 * E16 + g16] = sd;
-    float t = sd * sd - SQ[((g16 >> 1) * EX + e16) * 2 + (g16 & 1)];
+    float t = sd * sd - sqd;
     float fo = g16 < NWV ? WP[g16 * EX + e16] : 0.f;
     // layer 2 (32 -> 8): this lane's two units times K1, then the same butterfly
     float h2[U2];
@@ -622,20 +613,13 @@ __global__ __launch_bounds__(1024) void deepfm_reduce_kernel(ReduceArgs r) { red
 size_t fused_lds_bytes(int F) { return (size_t)carve_of(F).total * sizeof(float); }
 
 // ------------------------------------------------------------------------------------------------
-// per-column sort of the de-duplication plan, three short kernels so that ~200 CUs work on it instead of F:
-//   colsort_chunk_kernel   each 1024-id chunk of a column: bitonic network in registers / wave shuffles / 3 LDS
-//                          exchange stages on 32-bit words (key << pos_bits | example)
-//   colsort_rank_kernel    final position of a word = sum over the column's sorted chunks of #(words < it)
-//                          (binary searches in LDS; words are unique, so positions are too) -> scatter
-//   colsort_heads_kernel   one workgroup per column: run heads, scan, perm / col_uid / col_seg / col_nu
+// per-column sort of the de-duplication plan (the DataGenerator contract gives every feature column its own contiguous
+// id range, so duplicates only occur inside a column): 32-bit words (key << pos_bits | example), key = id - col_lo.
 // ------------------------------------------------------------------------------------------------
-constexpr int CHK = 1024;      // ids per sort chunk (256 threads x 4)
 constexpr uint32_t PADW = 0xFFFFFFFFu;
 
 struct ColSortArgs {
-  int64_t B; int F; int64_t V; int key_bits; int pos_bits; int nch;
-  uint32_t* chunks;     // [F][nch][CHK] sorted chunks
-  uint32_t* sorted;     // [F][B]
+  int64_t B; int F; int64_t V; int key_bits; int pos_bits;
   int32_t* perm;        // [F][B]  sorted position -> example
   int64_t* col_uid;     // [F][B]  unique ids of the column, ascending (first col_nu[f] valid)
   int32_t* col_seg;     // [F][B+1] run starts in the column's sorted order (tail = B)
@@ -644,182 +628,147 @@ struct ColSortArgs {
   int32_t* dloc;        // [F][B] or null: run index of lookup (f, example) inside its column, sign bit = not the run's head
 };
 
-__global__ __launch_bounds__(256) void colsort_chunk_kernel(Cols cols, const int64_t* __restrict__ col_lo, ColSortArgs a) {
-  constexpr int NPT = 4;
-  __shared__ uint32_t buf[2][CHK];
-  const int tid = threadIdx.x;
-  const int ch = blockIdx.x, f = blockIdx.y;
+// ------------------------------------------------------------------------------------------------
+// ONE kernel: one 1024-thread workgroup per column sorts the column's <= 16384 words in LDS (stable LSD radix sort on
+// the key bits, 7 bits per pass, in place: every key is in a register between the barrier that ends the reads and the
+// one that starts the writes) and goes straight on to the run heads.  (Round 1 ran a chunk-sort / rank-merge / heads
+// chain of three latency-bound launches on ~200 CUs: 65 us for the plans of four batches against 42 us here on
+// 4 x F workgroups of 37 KB of LDS.)
+//   ranking: element e = wave*64*KPT + round*64 + lane, so (wave, round, lane) order is array order; lanes of equal
+//   digit are matched by 7 ballots, the lowest lane of a group bumps the wave's 16-bit counter of the digit (LDS
+//   operations of one wave complete in program order); a key's new place = digit base + counts of earlier waves + its
+//   rank in the wave.
+// ------------------------------------------------------------------------------------------------
+constexpr int OW_T = 1024, OW_W = OW_T / 64, OW_BINS = 128, OW_DB = 7;
+
+template <int KPT>
+__global__ __launch_bounds__(OW_T) void colsort_onewg_kernel(Cols cols, const int64_t* __restrict__ col_lo, ColSortArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t owl[];
+  constexpr int NW = OW_T * KPT;                       // padded word count
+  uint32_t* words = owl;                               // [NW]
+  unsigned short* cnt = reinterpret_cast<unsigned short*>(owl + NW);      // [OW_W][OW_BINS]
+  uint32_t* dbase = owl + NW + OW_W * OW_BINS / 2;     // [OW_BINS]
+  uint32_t* wtot = dbase + OW_BINS;                    // [OW_W] scratch of the block scans
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f = blockIdx.x;
+  const int64_t B = a.B;
   const int64_t lo = col_lo[f];
-  uint32_t v[NPT];
+  const int pb = a.pos_bits;
+  const uint32_t pmask = (1u << pb) - 1u;
+  // ---- load: word = (id - lo) << pos_bits | example; pad words sort last
   bool bad = false;
 #pragma unroll
-  for (int r = 0; r < NPT; ++r) {
-    int64_t b = (int64_t)ch * CHK + tid * NPT + r;
+  for (int r = 0; r < KPT; ++r) {
+    const int e = r * OW_T + tid;
     uint32_t w = PADW;
-    if (b < a.B) {
-      int64_t id = cols.p[f][b];
+    if (e < B) {
+      const int64_t id = cols.p[f][e];
       int64_t key = id - lo;
       if (key < 0 || key >= (int64_t(1) << a.key_bits) || (uint64_t)id >= (uint64_t)a.V) {
         bad = true;
         key = key < 0 ? 0 : (int64_t(1) << a.key_bits) - 1;
       }
-      w = ((uint32_t)key << a.pos_bits) | (uint32_t)b;
+      w = ((uint32_t)key << pb) | (uint32_t)e;
     }
-    v[r] = w;
+    words[e] = w;
   }
   if (bad && a.bad) *a.bad = 1;
-  int pp = 0;
-  for (int k = 2; k <= CHK; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      if (j < NPT) {                                   // both elements in this thread's registers
-#pragma unroll
-        for (int r = 0; r < NPT; ++r) {
-          int pr = r ^ j;
-          if (pr > r) {
-            bool asc = ((tid * NPT + r) & k) == 0;
-            uint32_t x = v[r], y = v[pr];
-            bool sw = asc ? (x > y) : (x < y);
-            v[r] = sw ? y : x;
-            v[pr] = sw ? x : y;
-          }
-        }
-      } else {
-        int jt = j / NPT;                              // partner thread = tid ^ jt, same register index
-        bool lower = (tid & jt) == 0;
-        bool asc = ((tid * NPT) & k) == 0;             // k > j >= NPT: the same for the thread's 4 elements
-        bool keep_min = (lower == asc);
-        if (jt < 64) {                                 // partner in the same wave
-#pragma unroll
-          for (int r = 0; r < NPT; ++r) {
-            uint32_t y = (uint32_t)__shfl_xor((int)v[r], jt, 64);
-            v[r] = keep_min ? (v[r] < y ? v[r] : y) : (v[r] > y ? v[r] : y);
-          }
-        } else {                                       // partner in another wave: exchange through LDS
-          uint32_t* mine = buf[pp] + tid * NPT;
-#pragma unroll
-          for (int r = 0; r < NPT; ++r) mine[r] = v[r];
-          __syncthreads();
-          const uint32_t* other = buf[pp] + (tid ^ jt) * NPT;
-#pragma unroll
-          for (int r = 0; r < NPT; ++r) {
-            uint32_t y = other[r];
-            v[r] = keep_min ? (v[r] < y ? v[r] : y) : (v[r] > y ? v[r] : y);
-          }
-          pp ^= 1;                                     // ping-pong: one barrier per exchange stage
-        }
-      }
-    }
-  }
-  uint32_t* out = a.chunks + ((int64_t)f * a.nch + ch) * CHK + tid * NPT;
-#pragma unroll
-  for (int r = 0; r < NPT; ++r) out[r] = v[r];
-}
-
-__global__ __launch_bounds__(256) void colsort_rank_kernel(ColSortArgs a) {
-  // the other chunks of the column pass through LDS one at a time (two 4-KB buffers, one barrier per chunk): 8 KB
-  // of LDS, so these workgroups fit next to the 134-KB workgroups of the fused kernel on a CU
-  __shared__ uint32_t buf[2][CHK];
-  const int tid = threadIdx.x;
-  const int ch = blockIdx.x, f = blockIdx.y;
-  const uint32_t* col = a.chunks + (int64_t)f * a.nch * CHK;
-  uint32_t x[4];
-  int pos[4];
-  {
-    uint4 own = reinterpret_cast<const uint4*>(col + (int64_t)ch * CHK)[tid];
-    x[0] = own.x; x[1] = own.y; x[2] = own.z; x[3] = own.w;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) pos[r] = tid * 4 + r;    // words < x in the own (sorted, unique) chunk
-  }
-  int pp = 0;
-  for (int c2 = 0; c2 < a.nch; ++c2) {
-    if (c2 == ch) continue;
-    reinterpret_cast<uint4*>(buf[pp])[tid] = reinterpret_cast<const uint4*>(col + (int64_t)c2 * CHK)[tid];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  // ---- radix passes over the key bits
+  for (int shift = pb; shift < pb + a.key_bits; shift += OW_DB) {
+    reinterpret_cast<uint32_t*>(cnt)[tid] = 0;         // OW_W*OW_BINS/2 = 1024 words
     __syncthreads();
-    const uint32_t* cc = buf[pp];
+    uint32_t w[KPT];
+    unsigned short loc[KPT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int lo = 0;                                        // lower bound: number of words < x
+    for (int r = 0; r < KPT; ++r) w[r] = words[wave * (64 * KPT) + r * 64 + lane];
 #pragma unroll
-      for (int step = CHK / 2; step > 0; step >>= 1)
-        if (cc[lo + step - 1] < x[r]) lo += step;
-      if (cc[lo] < x[r]) ++lo;                           // CHK is a power of two: one last probe
-      pos[r] += lo;
+    for (int r = 0; r < KPT; ++r) {
+      const uint32_t d = (w[r] >> shift) & (OW_BINS - 1);
+      unsigned long long m = ~0ull;
+#pragma unroll
+      for (int b = 0; b < OW_DB; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+      }
+      const unsigned short old = cnt[wave * OW_BINS + d];
+      if ((m & lt) == 0) cnt[wave * OW_BINS + d] = (unsigned short)(old + __popcll(m));
+      loc[r] = (unsigned short)(old + __popcll(m & lt));
     }
-    pp ^= 1;
-  }
+    __syncthreads();                                   // every word is in a register: the array may be overwritten
+    if (tid < OW_BINS) {                               // per digit: counts -> exclusive prefix over the waves, total
+      uint32_t run = 0;
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
-    if (x[r] != PADW) a.sorted[(int64_t)f * a.B + pos[r]] = x[r];
-}
-
-// One workgroup per 1024 sorted positions of a column (grid nch x F, like the two kernels before it), so that ~200 CUs
-// share the work instead of F.  Every workgroup counts the run heads of the WHOLE column itself (B <= 16384 words out
-// of L2: heads before its slice = its rank offset, heads in all = col_nu) -- no second pass, no cross-workgroup wait.
-__global__ __launch_bounds__(256) void colsort_heads_kernel(const int64_t* __restrict__ col_lo, ColSortArgs a) {
-  __shared__ int wred[2][4];
-  __shared__ int wtot[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q = blockIdx.x, f = blockIdx.y;
-  const int64_t B = a.B;
-  const int64_t lo = col_lo[f];
-  const uint32_t* srt = a.sorted + (int64_t)f * B;
-  const int pb = a.pos_bits;
-  const uint32_t pmask = (1u << pb) - 1u;
-  const int64_t s_begin = (int64_t)q * CHK;
-  // heads of the column before this slice / in total
-  int before = 0, all = 0;
-  for (int64_t s = tid; s < B; s += 256) {
-    int h = (s == 0 || (srt[s] >> pb) != (srt[s - 1] >> pb)) ? 1 : 0;
-    all += h;
-    if (s < s_begin) before += h;
+      for (int q = 0; q < OW_W; ++q) {
+        const uint32_t c = cnt[q * OW_BINS + tid];
+        cnt[q * OW_BINS + tid] = (unsigned short)run;
+        run += c;
+      }
+      // exclusive scan of the 128 totals (two waves)
+      uint32_t incl = run;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+      }
+      if (lane == 63) wtot[wave] = incl;
+      dbase[tid] = incl - run;                         // within the wave; wave 1 adds wave 0's total below
+    }
+    __syncthreads();
+    if (tid >= 64 && tid < OW_BINS) dbase[tid] += wtot[0];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < KPT; ++r) {
+      const uint32_t d = (w[r] >> shift) & (OW_BINS - 1);
+      words[dbase[d] + cnt[wave * OW_BINS + d] + loc[r]] = w[r];
+    }
+    __syncthreads();
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    before += __shfl_xor(before, o, 64);
-    all += __shfl_xor(all, o, 64);
-  }
-  if (lane == 0) { wred[0][wave] = before; wred[1][wave] = all; }
-  __syncthreads();
-  before = wred[0][0] + wred[0][1] + wred[0][2] + wred[0][3];
-  all = wred[1][0] + wred[1][1] + wred[1][2] + wred[1][3];
-  // own slice: thread owns 4 consecutive sorted positions
-  const int64_t s0 = s_begin + (int64_t)tid * 4;
-  uint32_t v[4];
-  bool hd[4];
+  // ---- run heads: thread t owns the KPT consecutive sorted positions from t*KPT
+  const int s0 = tid * KPT;
+  uint32_t v[KPT];
+  bool hd[KPT];
   int heads = 0;
-  uint32_t prev = (s0 > 0 && s0 - 1 < B) ? srt[s0 - 1] : PADW;
+  uint32_t prev = s0 > 0 ? words[s0 - 1] : PADW;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    int64_t s = s0 + r;
-    bool valid = s < B;
-    v[r] = valid ? srt[s] : PADW;
-    uint32_t pk = (r == 0 ? prev : v[r - 1]) >> pb;
-    hd[r] = valid && (s == 0 || (v[r] >> pb) != pk);
+  for (int r = 0; r < KPT; ++r) {
+    const int sp = s0 + r;
+    v[r] = words[sp];
+    const uint32_t pk = (r == 0 ? prev : v[r - 1]) >> pb;
+    hd[r] = sp < B && (sp == 0 || (v[r] >> pb) != pk);
     heads += hd[r] ? 1 : 0;
-    if (valid) a.perm[(int64_t)f * B + s] = (int32_t)(v[r] & pmask);
   }
   int incl = heads;
+#pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    int t = __shfl_up(incl, o, 64);
+    const int t = __shfl_up(incl, o, 64);
     if (lane >= o) incl += t;
   }
-  if (lane == 63) wtot[wave] = incl;
+  if (lane == 63) wtot[wave] = (uint32_t)incl;
   __syncthreads();
-  int woff = 0;
-  for (int w = 0; w < wave; ++w) woff += wtot[w];
-  int rank = before + woff + incl - heads;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    int64_t s = s0 + r;
-    if (hd[r]) {
-      a.col_uid[(int64_t)f * B + rank] = lo + (int64_t)(v[r] >> pb);
-      a.col_seg[(int64_t)f * (B + 1) + rank] = (int32_t)s;
-      ++rank;
-    }
-    // position 0 is always a head, so rank >= 1 here: the run this position belongs to is rank - 1
-    if (a.dloc && s < B) a.dloc[(int64_t)f * B + (v[r] & pmask)] = hd[r] ? rank - 1 : (int32_t)((uint32_t)(rank - 1) | 0x80000000u);
-    if (s < B && s + 1 >= all) a.col_seg[(int64_t)f * (B + 1) + s + 1] = (int32_t)B;   // tail [all .. B] = B
+  int woff = 0, all = 0;
+  for (int q = 0; q < OW_W; ++q) {
+    const int c = (int)wtot[q];
+    if (q < wave) woff += c;
+    all += c;
   }
-  if (q == 0 && tid == 0) a.col_nu[f] = all;
+  int rank = woff + incl - heads;
+#pragma unroll
+  for (int r = 0; r < KPT; ++r) {
+    const int sp = s0 + r;
+    if (sp < B) {
+      a.perm[(int64_t)f * B + sp] = (int32_t)(v[r] & pmask);
+      if (hd[r]) {
+        a.col_uid[(int64_t)f * B + rank] = lo + (int64_t)(v[r] >> pb);
+        a.col_seg[(int64_t)f * (B + 1) + rank] = sp;
+        ++rank;
+      }
+      if (a.dloc) a.dloc[(int64_t)f * B + (v[r] & pmask)] = hd[r] ? rank - 1 : (int32_t)((uint32_t)(rank - 1) | 0x80000000u);
+      if (sp + 1 >= all) a.col_seg[(int64_t)f * (B + 1) + sp + 1] = (int32_t)B;     // tail [all .. B] = B
+    }
+  }
+  if (tid == 0) a.col_nu[f] = all;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1329,9 +1278,7 @@ extern "C" int rec_deepfm_fused_post_direct_adam_f32(int F, int64_t B, const flo
 
 extern "C" size_t rec_colsort_workspace_bytes(int64_t B, int F) {
   if (B <= 0 || F <= 0) return 0;
-  int64_t np = CHK;
-  while (np < B) np <<= 1;
-  return sizeof(uint32_t) * (size_t)F * ((size_t)np + (size_t)B) + 256;
+  return 256;      // the sort runs in LDS; the argument is kept for callers written against the three-kernel version
 }
 
 static int colsort_plan(const int64_t* const* cols_host, int F, int64_t B, int64_t V, const int64_t* col_lo,
@@ -1352,20 +1299,28 @@ static int colsort_plan(const int64_t* const* cols_host, int F, int64_t B, int64
     if (!cols_host[f]) return REC_E_ARG;
     cp.p[f] = cols_host[f];
   }
-  int64_t np = CHK;
-  while (np < B) np <<= 1;
-  int nch = (int)(np / CHK);
-  uint32_t* chunks = (uint32_t*)workspace;
-  uint32_t* sorted = chunks + (size_t)F * np;
-  ColSortArgs a{B, F, V, key_bits, pos_bits, nch, chunks, sorted, perm, col_uid, col_seg, col_nu, bad_flag, dloc};
+  ColSortArgs a{B, F, V, key_bits, pos_bits, perm, col_uid, col_seg, col_nu, bad_flag, dloc};
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(colsort_chunk_kernel, dim3(nch, F), dim3(256), 0, st, cp, col_lo, a);
-  REC_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsort_rank_kernel, dim3(nch, F), dim3(256), 0, st, a);
-  REC_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsort_heads_kernel, dim3(nch, F), dim3(256), 0, st, col_lo, a);
-  REC_LAUNCH_CHECK();
-  return REC_OK;
+  // one workgroup per column (LDS radix sort + run heads in one launch); columns longer than 16 x 1024 do not occur
+  // (B <= 16384)
+  {
+    const int kpt = B <= 8192 ? 8 : 16;
+    const size_t lds = sizeof(uint32_t) * ((size_t)OW_T * kpt + OW_W * OW_BINS / 2 + OW_BINS + OW_W);
+    hipError_t e;
+    if (kpt == 8) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(colsort_onewg_kernel<8>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(colsort_onewg_kernel<8>, dim3(F), dim3(OW_T), lds, st, cp, col_lo, a);
+    } else {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(colsort_onewg_kernel<16>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(colsort_onewg_kernel<16>, dim3(F), dim3(OW_T), lds, st, cp, col_lo, a);
+    }
+    REC_LAUNCH_CHECK();
+    return REC_OK;
+  }
 }
 
 extern "C" int rec_colsort_plan_i64(const int64_t* const* cols_host, int F, int64_t B, int64_t V, const int64_t* col_lo,
