@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
-"""profiles/r01_pmc_traffic.json from the two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE; separate runs, as
+"""profiles/r02_pmc_traffic.json from the two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE; separate runs, as
 MI355X_MICROARCH.md's HBM section prescribes):
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -o f -- python3 bench.py --steps 20 --warmup 8 \
-        --no-graph --no-cpu-baseline --adam-steps 0
+        --no-cpu-baseline --adam-steps 0
     rocprofv3 --pmc WRITE_SIZE ... -d gpurun_out/pmc_w -o w -- (same command)
     python scripts/pmc_traffic.py gpurun_out/pmc_f/f_counter_collection.csv gpurun_out/pmc_w/w_counter_collection.csv
 
 Units: KB per dispatch.  gfx950 correction: FETCH_SIZE reads exactly 1/2 of the fetched bytes, WRITE_SIZE is exact
--> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
+-> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  Kernels that bench.py launches at two sizes (the row gathers: 2^20
+lookups and the config's batch) are taken at their LARGEST grid, the one the roofline records quote.
 """
 import csv
 import json
@@ -17,31 +18,42 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KEEP = ["colsort_chunk_kernel", "colsort_rank_kernel", "colsort_heads_kernel", "deepfm_fwd_bwd_kernel",
-        "deepfm_reduce_kernel", "deepfm_post_kernel", "colseg_sum_kernel", "index_pack_kernel", "emb_fm_fwd_vec_kernel"]
+KEEP = ["colsort_onewg_kernel", "deepfm_fwd_bwd_kernel", "deepfm_post_direct_kernel", "emb_fm_fwd_vec_kernel",
+        "gather_rows_kernel_e32", "gather_rows_kernel_e64"]
+
+
+def key_of(name):
+    m = re.search(r"gather_rows_kernel<(\d+)", name)
+    if m:
+        return "gather_rows_kernel_e%d" % (4 * int(m.group(1)))
+    m = re.search(r"(\w+_kernel)\b", name)
+    return m.group(1) if m else None
 
 
 def per_kernel(path, counter):
-    acc = {}
+    rows = {}
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        m = re.search(r"(\w+_kernel)\b", r["Kernel_Name"])
-        if not m or m.group(1) not in KEEP:
+        k = key_of(r["Kernel_Name"])
+        if k not in KEEP:
             continue
-        s = acc.setdefault(m.group(1), [0.0, 0])
-        s[0] += float(r["Counter_Value"])
-        s[1] += 1
+        rows.setdefault(k, []).append((int(r.get("Grid_Size", 0) or 0), float(r["Counter_Value"])))
+    acc = {}
+    for k, lst in rows.items():
+        gmax = max(g for g, _ in lst)
+        vals = [v for g, v in lst if g == gmax]
+        acc[k] = (sum(vals), len(vals))
     return acc
 
 
 def main(fetch_csv, write_csv):
     f, w = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
     out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --steps 20 --warmup 8 "
-                   "--no-graph (1 x MI355X, DeepFM 10M x 16d, B=8192). Units: KB per dispatch. gfx950 correction "
-                   "(MI355X_MICROARCH.md, section HBM): FETCH_SIZE reads exactly 1/2 of the fetched bytes, WRITE_SIZE is "
-                   "exact -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024. Calibration on a known count: the gather "
-                   "kernel reads 212,992 lookups x one 128-B line + 1.7 MB of ids = 29.0 MB.",
+                   "(1 x MI355X, DeepFM 10M x 16d, B=8192; row gathers at 2^20 lookups). Units: KB per dispatch. gfx950 "
+                   "correction (MI355X_MICROARCH.md, section HBM): FETCH_SIZE reads exactly 1/2 of the fetched bytes, "
+                   "WRITE_SIZE is exact -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024. Calibration on a known count: the "
+                   "gather + FM kernel reads 212,992 lookups x one 128-B line + 1.7 MB of ids = 29.0 MB.",
            "kernels": {}}
     for k in KEEP:
         if k in f and k in w:
@@ -49,9 +61,9 @@ def main(fetch_csv, write_csv):
             out["kernels"][k] = {"FETCH_SIZE_KB_avg": round(fa, 1), "dispatches_fetch": f[k][1],
                                  "WRITE_SIZE_KB_avg": round(wa, 1), "dispatches_write": w[k][1],
                                  "hbm_bytes_per_launch_corrected": int((2 * fa + wa) * 1024)}
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"), "w"), indent=1)
     for k, v in out["kernels"].items():
-        print("%-26s %8.2f MB" % (k, v["hbm_bytes_per_launch_corrected"] / 1e6))
+        print("%-28s %8.2f MB" % (k, v["hbm_bytes_per_launch_corrected"] / 1e6))
 
 
 if __name__ == "__main__":
