@@ -44,6 +44,9 @@ def parse():
                          "memory-side cache: no step finds its rows cached from the previous cycle)")
     ap.add_argument("--cycle", type=int, default=4, help="steps per captured hipGraph (<= 8; must divide --resident)")
     ap.add_argument("--step-graphs", action="store_true", help="one hipGraph per step instead of one per 4-step cycle")
+    ap.add_argument("--sharded-graph", action="store_true",
+                    help="row-sharded step: capture each cycle of steps, RCCL collectives included, in one hipGraph "
+                         "(verified at world size 1 only; the default issues the sharded step eagerly)")
     ap.add_argument("--generic", action="store_true", help="use the generic ~35-kernel step instead of the fused one")
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1: independent full-table replicas instead of the row-sharded table + RCCL all-to-all")
@@ -211,6 +214,11 @@ def main():
                 b0 = i % n_batches
                 step.many(batches[b0:b0 + n - i], then=[batches[(b0 + n - i + j) % n_batches] for j in range(Cy)])
                 i = n
+        if sharded_mode and args.sharded_graph:
+            while n - i >= Cy:
+                b0 = i % n_batches
+                step.many(batches[b0:b0 + Cy])
+                i += Cy
         while i < n:
             run(i)
             i += 1
@@ -440,11 +448,15 @@ def main():
                                           "all-reduce of dense gradients") if sharded_mode else
                           ("1 process per GPU, independent full-table replicas" if world > 1 else "single GPU"),
                           "global_batch": world * B,
-                          "hipgraph": ((not args.no_graph) and not sharded_mode) and
+                          "hipgraph": ("one graph per %d steps incl. the RCCL collectives" % Cy
+                                       if args.sharded_graph else False) if sharded_mode else
+                          (not args.no_graph) and
                           ("one graph per %d steps, %d resident batches" % (Cy, n_batches) if cycle else "one per step"),
-                          "step": "sharded, de-duplicate first: per-column sort plan (next batch, second stream), all-to-all "
-                          "of unique ids, owner gather, all-to-all of rows, fused fwd+bwd on them, per-id sums, all-to-all "
-                          "of row gradients, owner rank-merge" if sharded_mode else
+                          "step": "sharded, de-duplicate first, fixed-capacity exchanges (constant split sizes, nothing read "
+                          "back by the host): per-column sort plan + id message + owner rank-merge for the next batch on a "
+                          "second stream (own communicator), owner gather, all-to-all of rows, fused fwd+bwd on them, "
+                          "per-id sums into the send slots, all-to-all of row gradients, owner sums"
+                          if sharded_mode else
                           "generic" if args.generic else
                           "fused: fwd+bwd kernel writing value rows straight to their de-duplicated slots (plan complete "
                           "before the kernel), then reduction + remaining segment sums in one launch; de-duplication "

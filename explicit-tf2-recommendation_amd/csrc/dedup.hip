@@ -256,9 +256,12 @@ __device__ __forceinline__ int block_sum_256(int v, int* sh) {
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// n_dev (optional): the number of valid keys lives on the device (<= n, the capacity the grid was sized for)
 __global__ __launch_bounds__(256) void count_heads_kernel(const uint32_t* __restrict__ keys, int64_t n,
-                                                          int32_t* __restrict__ tile_heads) {
+                                                          int32_t* __restrict__ tile_heads,
+                                                          const int64_t* __restrict__ n_dev = nullptr) {
   __shared__ int sh[4];
+  if (n_dev) n = *n_dev < n ? *n_dev : n;
   int64_t base = (int64_t)blockIdx.x * TILE;
   int cnt = 0;
 #pragma unroll
@@ -276,9 +279,12 @@ __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t* __restric
                                                        const int32_t* __restrict__ tile_heads, int n_tiles,
                                                        int64_t* __restrict__ uniq_ids,
                                                        int32_t* __restrict__ seg_start,
-                                                       int64_t* __restrict__ n_uniq) {
+                                                       int64_t* __restrict__ n_uniq,
+                                                       const int64_t* __restrict__ n_dev = nullptr) {
   __shared__ int sh[4];
   __shared__ int wave_tot[4];
+  const int64_t cap = n;                          // slots of uniq_ids / seg_start (+1) to fill
+  if (n_dev) n = *n_dev < n ? *n_dev : n;
   int before = 0, all = 0;
   for (int t = threadIdx.x; t < n_tiles; t += 256) {
     int h = tile_heads[t];
@@ -326,13 +332,14 @@ __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t* __restric
     }
   }
   // tail padding: slots >= n_uniq become empty runs of a valid id (keys[0] = the smallest id)
-  uint32_t pad = keys[0];
+  uint32_t pad = n > 0 ? keys[0] : 0u;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     int64_t i = i0 + k;
-    if (i < n && i >= all) uniq_ids[i] = (int64_t)pad;
-    if (i < n && i + 1 >= all) seg_start[i + 1] = (int32_t)n;  // covers seg_start[n_uniq .. n]
+    if (i < cap && i >= all) uniq_ids[i] = (int64_t)pad;
+    if (i < cap && i + 1 >= all) seg_start[i + 1] = (int32_t)n;  // covers seg_start[n_uniq .. cap]
   }
+  if (i0 == 0 && all == 0) seg_start[0] = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *n_uniq = all;
   }
@@ -565,6 +572,49 @@ __global__ __launch_bounds__(256) void merge_rank_kernel(const int64_t* __restri
   perm[rank] = (int32_t)e;
 }
 
+
+// The same union for lists that arrive in fixed-capacity slabs (rec_colsort_shard_map_fixed_i64's message layout): list q
+// starts at msg[q*(hdr+cap) + hdr], msg[q*(hdr+cap)] of its cap slots are used.  perm[rank] = q*cap + j = the row of the
+// element in the [n_lists*cap, .] payload buffer that travels beside the ids; *n_valid = total number of ids.
+__global__ __launch_bounds__(256) void merge_rank_strided_kernel(const int64_t* __restrict__ msg, int n_lists,
+                                                                 int64_t cap, int hdr, uint32_t* __restrict__ keys_out,
+                                                                 int32_t* __restrict__ perm,
+                                                                 int64_t* __restrict__ n_valid) {
+  __shared__ int cnt[MAX_LISTS];
+  const int64_t stride = cap + hdr;
+  if ((int)threadIdx.x < n_lists) {
+    int64_t c = msg[(int64_t)threadIdx.x * stride];
+    cnt[threadIdx.x] = (int)(c < 0 ? 0 : (c > cap ? cap : c));
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int64_t a = 0;
+    for (int q = 0; q < n_lists; ++q) a += cnt[q];
+    *n_valid = a;
+  }
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int s = (int)(e / cap);
+  if (s >= n_lists) return;
+  const int64_t j = e - (int64_t)s * cap;
+  if (j >= cnt[s]) return;
+  const int64_t id = msg[(int64_t)s * stride + hdr + j];
+  int64_t rank = j;
+  for (int q = 0; q < n_lists; ++q) {
+    if (q == s) continue;
+    const int64_t* lst = msg + (int64_t)q * stride + hdr;
+    int lo = 0, hi = cnt[q];                        // first position whose id is > id (q < s) or >= id (q > s)
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      int64_t v = lst[mid];
+      bool before = q < s ? v <= id : v < id;
+      if (before) lo = mid + 1; else hi = mid;
+    }
+    rank += lo;
+  }
+  keys_out[rank] = (uint32_t)id;
+  perm[rank] = (int32_t)e;
+}
+
 }  // namespace
 
 extern "C" size_t rec_dedup_workspace_bytes(int64_t n) {
@@ -668,6 +718,33 @@ extern "C" int rec_dedup_plan_sorted_lists_i64(const int64_t* ids, int64_t n, co
   REC_LAUNCH_CHECK();
   hipLaunchKernelGGL(finalize_kernel, dim3(n_tiles), dim3(256), 0, st, keys_out, n, tile_heads, n_tiles, uniq_ids,
                      seg_start, n_uniq);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_dedup_plan_sorted_slabs_i64(const int64_t* msg, int n_lists, int64_t cap, int64_t V,
+                                               int64_t* uniq_ids, int32_t* seg_start, int32_t* perm, int64_t* n_uniq,
+                                               void* workspace, size_t workspace_bytes, void* stream) {
+  if (!msg || !uniq_ids || !seg_start || !perm || !n_uniq || !workspace || cap <= 0 || V <= 0 || n_lists <= 0)
+    return REC_E_ARG;
+  const int64_t n = (int64_t)n_lists * cap;
+  if (n >= (int64_t(1) << 31) || V > (int64_t(1) << 32) || n_lists > MAX_LISTS) return REC_E_UNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  Layout L = make_layout(n);
+  if (workspace_bytes < L.total) return REC_E_WORKSPACE;
+  char* ws = (char*)workspace;
+  uint32_t* keys_out = (uint32_t*)(ws + L.keys_out);
+  int32_t* tile_heads = (int32_t*)(ws + L.tile_heads);
+  int64_t* n_valid = (int64_t*)(ws + L.tot);      // the radix sort's digit totals are not used on this path
+  hipLaunchKernelGGL(merge_rank_strided_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, st, msg, n_lists, cap,
+                     2, keys_out, perm, n_valid);
+  REC_LAUNCH_CHECK();
+  int n_tiles = (int)ceil_div64(n, TILE);
+  hipLaunchKernelGGL(count_heads_kernel, dim3(n_tiles), dim3(256), 0, st, keys_out, n, tile_heads,
+                     (const int64_t*)n_valid);
+  REC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(finalize_kernel, dim3(n_tiles), dim3(256), 0, st, keys_out, n, tile_heads, n_tiles, uniq_ids,
+                     seg_start, n_uniq, (const int64_t*)n_valid);
   REC_LAUNCH_CHECK();
   return REC_OK;
 }

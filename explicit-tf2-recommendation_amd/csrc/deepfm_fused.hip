@@ -781,6 +781,9 @@ struct ColSegArgs {
   // lazy (touched-rows) Adam applied to a row the moment its gradient is final (direct-mode post launch only; table ==
   // null: off).  table: fused rows [V, 32] = [embed 16 | w | pad]; m_e, v_e [V,16]; m_w, v_w [V]
   float* table; float* m_e; float* v_e; float* m_w; float* v_w; int64_t V; float lr_t, b1, b2, eps;
+  // fixed-capacity exchange layout (sharded step): slot of every unique id (index = its rank in the batch's ascending
+  // list) inside the [owners x capacity] send buffer; null = the compact list itself
+  const int32_t* slot_map;
 };
 
 // m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2 ; var <- var - lr_t m / (sqrt(v) + eps)   (rec_adam_rows_f32's formula)
@@ -897,7 +900,9 @@ __device__ __forceinline__ void colseg_body(const ColSegArgs& k, int bidx) {
   if (live) {
     dst = before + u;
     idv = col_uid[(int64_t)f * B + u];
+    if (k.slot_map) dst = k.slot_map[dst];
   } else {
+    if (k.slot_map) return;                      // the unused slots of a send buffer are never read by the owner
     // padded tail: slot = total + rank among the non-live groups; id = the smallest id of column 0
     dst = total + ((int64_t)f * B - before) + (u - nu);
     idv = col_uid[0];
@@ -911,8 +916,8 @@ __device__ __forceinline__ void colseg_body(const ColSegArgs& k, int bidx) {
     g_embed[dst * 4 + c] = acc;
     if (c == 0) g_w[dst] = accw;
   }
-  if (c == 0) uniq_ids[dst] = idv;
-  if (grp == 0 && c == 0) *n_uniq = total;
+  if (c == 0 && uniq_ids) uniq_ids[dst] = idv;
+  if (grp == 0 && c == 0 && n_uniq) *n_uniq = total;
 }
 
 __global__ __launch_bounds__(256) void colseg_sum_kernel(ColSegArgs k) { colseg_body(k, (int)blockIdx.x); }
@@ -1184,8 +1189,11 @@ static int launch_post(bool direct, int F, int64_t B, const float* gz, const flo
                        void* stream, const ColSegArgs* adam = nullptr) {
   if (B <= 0 || F <= 0 || F > 28) return REC_E_ARG;
   if (!gz || !vals || !dK0 || !db0 || !dK1 || !db1 || !dK2 || !db2 || !dbias || !loss || !workspace || !perm ||
-      !col_uid || !col_seg || !col_nu || !uniq_ids || !g_embed_rows || !n_uniq || (!packed && !g_w_rows))
+      !col_uid || !col_seg || !col_nu || !g_embed_rows || (!packed && !g_w_rows))
     return REC_E_ARG;
+  const bool slots = adam && adam->slot_map;
+  if (!slots && (!uniq_ids || !n_uniq)) return REC_E_ARG;
+  if (slots && (direct || !packed)) return REC_E_UNSUPPORTED;
   if (direct && packed) return REC_E_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(vals) & 15) != 0 || (reinterpret_cast<uintptr_t>(g_embed_rows) & 15) != 0)
     return REC_E_UNSUPPORTED;
@@ -1198,8 +1206,10 @@ static int launch_post(bool direct, int F, int64_t B, const float* gz, const flo
   ReduceArgs r{dK0part, small, nwg, D, B, dK0, dK1, db0, db1, dK2, db2, dbias, loss};
   ColSegArgs k{(const float4*)vals, gz, perm, col_uid, col_seg, col_nu, B, F, uniq_ids, (float4*)g_embed_rows,
                packed ? (float*)nullptr : g_w_rows, n_uniq, packed ? 1 : 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f,
-               0.f, 0.f, 0.f};
-  if (adam) {
+               0.f, 0.f, 0.f, nullptr};
+  if (slots) {
+    k.slot_map = adam->slot_map;
+  } else if (adam) {
     k.table = adam->table; k.m_e = adam->m_e; k.v_e = adam->v_e; k.m_w = adam->m_w; k.v_w = adam->v_w; k.V = adam->V;
     k.lr_t = adam->lr_t; k.b1 = adam->b1; k.b2 = adam->b2; k.eps = adam->eps;
   }
@@ -1221,6 +1231,20 @@ extern "C" int rec_deepfm_fused_post_f32(int F, int64_t B, const float* gz, cons
                                          void* stream) {
   return launch_post(false, F, B, gz, vals, dK0, db0, dK1, db1, dK2, db2, dbias, loss, workspace, perm, col_uid, col_seg,
                      col_nu, uniq_ids, g_embed_rows, g_w_rows, n_uniq, packed, stream);
+}
+
+// sharded step with fixed-capacity exchanges: the packed rows [embed 16 | w | 0 0 0] of the batch's unique ids go to the
+// slots rec_colsort_shard_map_fixed_i64 gave them inside g_rows [owners * capacity, 20]; unused slots are not written
+extern "C" int rec_deepfm_fused_post_slots_f32(int F, int64_t B, const float* gz, const float* vals, float* dK0,
+                                               float* db0, float* dK1, float* db1, float* dK2, float* db2, float* dbias,
+                                               float* loss, void* workspace, const int32_t* perm, const int64_t* col_uid,
+                                               const int32_t* col_seg, const int32_t* col_nu, const int32_t* slot_map,
+                                               float* g_rows, void* stream) {
+  if (!slot_map) return REC_E_ARG;
+  ColSegArgs a{};
+  a.slot_map = slot_map;
+  return launch_post(false, F, B, gz, vals, dK0, db0, dK1, db1, dK2, db2, dbias, loss, workspace, perm, col_uid, col_seg,
+                     col_nu, nullptr, g_rows, nullptr, nullptr, 1, stream, &a);
 }
 
 // direct mode: the plan (rec_colsort_plan_dest_i64) exists BEFORE the fused kernel runs; the kernel writes the value row

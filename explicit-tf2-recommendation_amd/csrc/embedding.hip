@@ -102,6 +102,47 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   }
 }
 
+// Owner-side gather of a fixed-capacity exchange (sharded step): n_lists id lists at a stride of hdr + cap int64 words,
+// word 0 of a list = how many of its cap slots are used.  Row (q, j) of out [n_lists * cap, 4 * LPR] is read only when
+// j < count_q; the unused slots are neither read nor written (nobody indexes them).
+template <int LPR, int UNR>
+__global__ __launch_bounds__(256) void gather_lists_kernel(const float* __restrict__ table, int64_t V, int64_t ld,
+                                                           const int64_t* __restrict__ msg, int64_t cap, int hdr,
+                                                           int64_t n, float4* __restrict__ out, int* oob) {
+  constexpr int R = 256 / LPR;
+  const int c = threadIdx.x & (LPR - 1), rs = threadIdx.x / LPR;
+  const int64_t r0 = (int64_t)blockIdx.x * (R * UNR) + rs;
+  const int64_t stride = cap + hdr;
+  int64_t id[UNR];
+  bool used[UNR];
+#pragma unroll
+  for (int j = 0; j < UNR; ++j) {
+    const int64_t r = r0 + (int64_t)j * R;
+    used[j] = false;
+    id[j] = -1;
+    if (r < n) {
+      const int64_t q = r / cap, jj = r - q * cap;
+      used[j] = jj < msg[q * stride];
+      if (used[j]) id[j] = msg[q * stride + hdr + jj];
+    }
+  }
+  float4 v[UNR];
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < UNR; ++j) {
+    const bool ok = (uint64_t)id[j] < (uint64_t)V;
+    bad |= used[j] && !ok;
+    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) v[j] = *reinterpret_cast<const float4*>(table + id[j] * ld + 4 * c);
+  }
+  if (bad && oob) *oob = 1;
+#pragma unroll
+  for (int j = 0; j < UNR; ++j) {
+    const int64_t r = r0 + (int64_t)j * R;
+    if (used[j]) out[r * LPR + c] = v[j];
+  }
+}
+
 __global__ __launch_bounds__(256) void gather_scalar_kernel(const float* __restrict__ table, int64_t V, int E,
                                                             int64_t ld, const int64_t* __restrict__ idx, int64_t n,
                                                             float* __restrict__ out, int* oob) {
@@ -153,6 +194,32 @@ extern "C" int rec_emb_gather_f32(const float* table, int64_t V, int E, int64_t 
     hipLaunchKernelGGL(gather_scalar_kernel, dim3((unsigned)ceil_div64(n * E, 256)), dim3(256), 0,
                        as_stream(stream), table, V, E, ld, idx, n, out, oob_flag);
   }
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_emb_gather_lists_f32(const float* table, int64_t V, int E, int64_t ld, const int64_t* msg,
+                                        int n_lists, int64_t cap, float* out, int* oob_flag, void* stream) {
+  if (V <= 0 || E <= 0 || ld < E || n_lists <= 0 || cap <= 0 || !table || !msg || !out) return REC_E_ARG;
+  if (!(vec4_ok(table, E, ld) && vec4_ok(out, E, E) && (E & (E - 1)) == 0 && E >= 4 && E <= 256))
+    return REC_E_UNSUPPORTED;
+  const int lpr = E / 4;
+  constexpr int UNR = 4;
+  const int64_t n = (int64_t)n_lists * cap;
+  const unsigned grid = (unsigned)ceil_div64(n, (256 / lpr) * UNR);
+#define GATHER_LISTS(L)                                                                                            \
+  hipLaunchKernelGGL((gather_lists_kernel<L, UNR>), dim3(grid), dim3(256), 0, as_stream(stream), table, V, ld, msg, cap, \
+                     2, n, (float4*)out, oob_flag)
+  switch (lpr) {
+    case 1: GATHER_LISTS(1); break;
+    case 2: GATHER_LISTS(2); break;
+    case 4: GATHER_LISTS(4); break;
+    case 8: GATHER_LISTS(8); break;
+    case 16: GATHER_LISTS(16); break;
+    case 32: GATHER_LISTS(32); break;
+    default: GATHER_LISTS(64); break;
+  }
+#undef GATHER_LISTS
   REC_LAUNCH_CHECK();
   return REC_OK;
 }

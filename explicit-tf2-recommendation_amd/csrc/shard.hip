@@ -200,6 +200,84 @@ __global__ __launch_bounds__(256) void shard_map_kernel(const int32_t* __restric
   if (tid < n_shard && cnt[tid]) atomicAdd(&send_counts[tid], (unsigned long long)cnt[tid]);
 }
 
+
+// ---- the same plan for FIXED-CAPACITY exchanges: every owner gets a slab of `cap` slots, whatever the batch holds, so
+// that the three payload exchanges of a step have constant sizes -- no count exchange, no host read, and the step can be
+// captured in a hipGraph.  cap >= the unique ids one batch can hold for one owner: the sum over the fields that intersect
+// the owner's block of min(B, overlap) (engine.ShardedDeepFMStep computes it from the field layout).
+//   msg[o][0] = unique ids of this batch owned by o, msg[o][1] = 0, msg[o][2 + j] = j-th of them as owner-local id
+//   uidx[f][example] = o * cap + j : the row of the lookup inside the [owners, cap] buffer the rows come back in
+//   slot_map[rank in the batch's ascending unique list] = o * cap + j : where the post launch puts the gradient row
+// The first unique id of owner o has rank start[o] = sum over the columns of (ids below o * rows_per_shard): one binary
+// search per (owner, column) per workgroup, in LDS.
+constexpr int MSG_HDR = 2;
+__global__ __launch_bounds__(256) void shard_map_fixed_kernel(
+    const int32_t* __restrict__ perm, const int64_t* __restrict__ col_uid, const int32_t* __restrict__ col_seg,
+    const int32_t* __restrict__ col_nu, int64_t B, int F, int64_t rows_per_shard, int n_shard, int64_t cap,
+    int64_t* __restrict__ msg, int64_t* __restrict__ uidx, int32_t* __restrict__ slot_map, int64_t* __restrict__ n_uniq,
+    int* __restrict__ oob) {
+  __shared__ int nu_s[REC_MAX_COLS];
+  __shared__ int start_s[MAX_SHARD + 1];
+  const int tid = threadIdx.x;
+  if (tid < F) nu_s[tid] = col_nu[tid];
+  if (tid <= n_shard) start_s[tid] = 0;
+  __syncthreads();
+  for (int j = tid; j < (n_shard - 1) * F; j += 256) {
+    const int o = 1 + j / F, q = j - (o - 1) * F;
+    const int64_t bound = (int64_t)o * rows_per_shard;
+    const int64_t* cu = col_uid + (int64_t)q * B;
+    int lo = 0, hi = nu_s[q];
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (cu[mid] < bound) lo = mid + 1; else hi = mid;
+    }
+    if (lo) atomicAdd(&start_s[o], lo);
+  }
+  int64_t total = 0;
+  for (int q = 0; q < F; ++q) total += nu_s[q];
+  __syncthreads();
+  if (tid == 0) start_s[n_shard] = (int)total;
+  __syncthreads();
+  const int64_t stride = cap + MSG_HDR;
+  const int64_t t = (int64_t)blockIdx.x * 256 + tid;
+  if (blockIdx.x == 0 && tid < n_shard) {
+    int cnt = start_s[tid + 1] - start_s[tid];
+    if (cnt > cap) {
+      if (oob) *oob = 1;                          // capacity too small for this batch (caller's bound was wrong)
+      cnt = (int)cap;
+    }
+    msg[(int64_t)tid * stride] = cnt;
+    msg[(int64_t)tid * stride + 1] = 0;
+  }
+  if (t == 0) *n_uniq = total;
+  const int f = (int)(t / B);
+  const int s = (int)(t - (int64_t)f * B);
+  if (f >= F) return;
+  int64_t before = 0;
+  for (int q = 0; q < f; ++q) before += nu_s[q];
+  const int nu = nu_s[f];
+  const int32_t* seg = col_seg + (int64_t)f * (B + 1);
+  int lo = 0, hi = nu - 1;                         // largest u with seg[u] <= s   (seg[0] = 0)
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (seg[mid] <= s) lo = mid; else hi = mid - 1;
+  }
+  const int64_t id = col_uid[(int64_t)f * B + lo];
+  int64_t o = id >= 0 ? id / rows_per_shard : -1;
+  if (o < 0 || o >= n_shard) {
+    if (oob) *oob = 1;
+    o = id < 0 ? 0 : n_shard - 1;
+  }
+  int64_t j = before + lo - start_s[(int)o];
+  if (j < 0 || j >= cap) j = 0;                    // only after an out-of-range id or a capacity overflow (flag is set)
+  const int64_t slot = o * cap + j;
+  uidx[(int64_t)f * B + perm[(int64_t)f * B + s]] = slot;
+  if (seg[lo] == s) {                              // run head: one thread per unique id
+    msg[o * stride + MSG_HDR + j] = id - o * rows_per_shard;
+    slot_map[before + lo] = (int32_t)slot;
+  }
+}
+
 }  // namespace
 
 extern "C" size_t rec_shard_bucketize_workspace_bytes(int64_t n, int n_shard) {
@@ -252,6 +330,21 @@ extern "C" int rec_colsort_shard_map_i64(const int32_t* perm, const int64_t* col
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(shard_map_kernel, dim3((unsigned)ceil_div64(B * F, 256)), dim3(256), 0, st, perm, col_uid, col_seg,
                      col_nu, B, F, rows_per_shard, n_shard, uid_local, uidx, (unsigned long long*)send_counts, n_uniq,
+                     oob_flag);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_colsort_shard_map_fixed_i64(const int32_t* perm, const int64_t* col_uid, const int32_t* col_seg,
+                                               const int32_t* col_nu, int64_t B, int F, int64_t rows_per_shard,
+                                               int n_shard, int64_t cap, int64_t* msg, int64_t* uidx, int32_t* slot_map,
+                                               int64_t* n_uniq, int* oob_flag, void* stream) {
+  if (!perm || !col_uid || !col_seg || !col_nu || !msg || !uidx || !slot_map || !n_uniq || B <= 0 || F <= 0 ||
+      rows_per_shard <= 0 || n_shard <= 0 || cap <= 0)
+    return REC_E_ARG;
+  if (n_shard > MAX_SHARD || F > REC_MAX_COLS || (int64_t)n_shard * cap >= (int64_t(1) << 31)) return REC_E_UNSUPPORTED;
+  hipLaunchKernelGGL(shard_map_fixed_kernel, dim3((unsigned)ceil_div64(B * F, 256)), dim3(256), 0, as_stream(stream),
+                     perm, col_uid, col_seg, col_nu, B, F, rows_per_shard, n_shard, cap, msg, uidx, slot_map, n_uniq,
                      oob_flag);
   REC_LAUNCH_CHECK();
   return REC_OK;

@@ -563,37 +563,34 @@ class DeepFMFusedStep:
         return out
 
 
-class _HostCounts:
-    """[2,P] split sizes on their way to the host: pinned buffer + event (both reused), read when the step that needs
-    them starts."""
-
-    def __init__(self, P):
-        self.host = torch.empty((2, P), dtype=torch.int64, pin_memory=True)
-        self.event = torch.cuda.Event()
-
-    def send(self, dev_counts):
-        self.host.copy_(dev_counts, non_blocking=True)
-        self.event.record()
-        return self
-
-    def get(self):
-        self.event.synchronize()
-        both = self.host.tolist()
-        return both[0], both[1]
+def exchange_capacity(field_dims, field_offsets, batch_size, rows_per_shard, n_shard):
+    """Slots per owner of a fixed-capacity exchange: the most unique ids ONE batch can hold for one owner =
+    max over owners of the sum over the fields that intersect the owner's block of min(B, overlap) (a field contributes
+    at most one id per example).  Rounded up to a multiple of 8."""
+    cap = 1
+    for o in range(n_shard):
+        lo, hi = o * rows_per_shard, (o + 1) * rows_per_shard
+        c = 0
+        for d, off in zip(field_dims, field_offsets):
+            ov = min(hi, int(off) + int(d)) - max(lo, int(off))
+            if ov > 0:
+                c += min(int(batch_size), ov)
+        cap = max(cap, c)
+    return (cap + 7) // 8 * 8
 
 
 class HipStepBackend:
-    """Device-side pieces of ShardedDeepFMStep, all HIP kernels on preallocated buffers.  The CPU gloo test
-    (tests/test_sharded.py) injects an oracle-backed stand-in with the same methods to exercise the exchange logic
+    """Device-side pieces of ShardedDeepFMStep, all HIP kernels on preallocated buffers of constant size.  The CPU gloo
+    test (tests/test_sharded.py) injects an oracle-backed stand-in with the same methods to exercise the exchange logic
     without a GPU; the product never does.
 
-    The host issues ~15 C-ABI calls and 4 collectives per step and must stay ahead of the GPU, so nothing here looks up
-    torch's current stream or builds pointer arrays more than once: `begin()` caches the stream handles of a step,
-    the per-plan pointer arrays are built at construction, the owner-side buffers only ever grow."""
+    The host issues ~10 C-ABI calls and 4 collectives per step and must stay ahead of the GPU, so nothing here looks up
+    torch's current stream or builds pointer arrays more than once: `begin()` caches the stream handles of a step, the
+    per-plan pointer arrays are built at construction, nothing is allocated per step and nothing is read back."""
 
     def __init__(self, step, field_dims, field_offsets):
         self.step = step
-        B, F, P = step.B, step.F, step.P
+        B, F, P, cap = step.B, step.F, step.P, step.cap
         dev = step.dev
         n = B * F
         self.max_key = max(int(d) for d in field_dims) - 1
@@ -604,30 +601,35 @@ class HipStepBackend:
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         i64 = dict(dtype=torch.int64, device=dev)
+        m = P * cap                                        # rows of every exchange buffer
         self.col_lo = torch.tensor([int(o) for o in field_offsets], **i64)
         self.bad_ids = torch.zeros(1, **i32)
+        self.o_ws_bytes = lib.rec_dedup_workspace_bytes(m)
         self.plans = [dict(perm=torch.empty((F, B), **i32), col_uid=torch.empty((F, B), **i64),
                            col_seg=torch.empty((F, B + 1), **i32), col_nu=torch.zeros(F, **i32),
-                           uid_local=torch.empty(n, **i64), uidx=torch.empty((F, B), **i64),
-                           counts2=torch.zeros((2, P), **i64),      # row 0: unique ids per owner, row 1: received
-                           n_uniq=torch.zeros(1, **i64)) for _ in range(2)]
+                           msg=torch.zeros((P, cap + 2), **i64), msg_theirs=torch.zeros((P, cap + 2), **i64),
+                           uidx=torch.empty((F, B), **i64), slot_map=torch.zeros(n, **i32), n_uniq=torch.zeros(1, **i64),
+                           # owner side: union of the P lists that arrive (depends on ids only: built with the plan)
+                           o_uniq=torch.empty(m, **i64), o_seg=torch.empty(m + 1, **i32), o_perm=torch.empty(m, **i32),
+                           o_nu=torch.zeros(1, **i64)) for _ in range(2)]
         for pl in self.plans:
-            pl["counts"], pl["recv"] = pl["counts2"][0], pl["counts2"][1]
             pl["uidx_arr"] = (C.c_void_p * F)(*[pl["uidx"][f].data_ptr() for f in range(F)])
-        self.host_counts = [_HostCounts(P) for _ in range(2)]
         self.sort_ws = [torch.empty(lib.rec_colsort_workspace_bytes(B, F), dtype=torch.uint8, device=dev)
                         for _ in range(2)]
+        self.o_ws = [torch.empty(self.o_ws_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
         self.gz = torch.empty(B, **f32)
         self.vals = torch.empty((n, 16), **f32)
-        self.uniq_ids = torch.empty(n, **i64)
-        self.grows = torch.empty((n, 20), **f32)          # [embed 16 | w | pad 3] per unique id: one exchange buffer
-        self.n_uniq = torch.zeros(1, **i64)
+        self.rows_out = torch.zeros((m, 32), **f32)        # owner-side gather result           -> C2
+        self.rows_local = torch.zeros((m, 32), **f32)      # C2 ->  the batch's rows, [owner, slot]
+        self.grows = torch.zeros((m, 20), **f32)           # [embed 16 | w | pad 3] per unique id -> C3
+        self.rows_theirs = torch.zeros((m, 20), **f32)     # C3 ->
+        self.o_rows = torch.empty((m, 20), **f32)
+        self.o_sws = torch.empty(lib.rec_segment_sum_workspace_bytes(m, 20), dtype=torch.uint8, device=dev)
         self.ws = torch.empty(lib.rec_deepfm_fused_workspace_bytes(B, F), dtype=torch.uint8, device=dev)
         self.side = torch.cuda.Stream(device=dev)
         self.side_ctx = torch.cuda.stream(self.side)
         self.side_st = C.c_void_p(self.side.cuda_stream)
         self.main, self.st = None, None
-        self._cap = 0                                     # owner-side capacity (ids received), grow-only
         self._arr_cache = {}
 
     # -- streams: the plan of the next batch depends on ids only and is built beside the current step
@@ -654,7 +656,8 @@ class HipStepBackend:
         return arr
 
     def plan(self, cols, buf, on_side=False):
-        """Per-column sort + unique (rec_colsort_plan_i64), then the exchange map (rec_colsort_shard_map_i64)."""
+        """Per-column sort + unique (rec_colsort_plan_i64), then the fixed-capacity exchange map
+        (rec_colsort_shard_map_fixed_i64): the id message, the slot of every lookup and of every unique id."""
         st_ = self.step
         B, F = st_.B, st_.F
         pl = self.plans[buf]
@@ -662,26 +665,32 @@ class HipStepBackend:
         check(lib.rec_colsort_plan_i64(self._col_arr(cols), F, B, st_.V, _p(self.col_lo), self.max_key, _p(pl["perm"]),
                                        _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.bad_ids),
                                        _p(self.sort_ws[buf]), st), "rec_colsort_plan_i64")
-        check(lib.rec_colsort_shard_map_i64(_p(pl["perm"]), _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), B, F,
-                                            st_.rows_per_shard, st_.P, _p(pl["uid_local"]), _p(pl["uidx"]),
-                                            _p(pl["counts"]), _p(pl["n_uniq"]), _p(st_.oob), st),
-              "rec_colsort_shard_map_i64")
+        check(lib.rec_colsort_shard_map_fixed_i64(_p(pl["perm"]), _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]),
+                                                  B, F, st_.rows_per_shard, st_.P, st_.cap, _p(pl["msg"]),
+                                                  _p(pl["uidx"]), _p(pl["slot_map"]), _p(pl["n_uniq"]), _p(st_.oob), st),
+              "rec_colsort_shard_map_fixed_i64")
         return pl
 
-    def counts_to_host(self, pl, buf):
-        return self.host_counts[buf].send(pl["counts2"])
+    def owner_plan(self, pl, buf, on_side=False):
+        """Union of the P ascending id lists that arrived (rank merge) as a segment plan over the payload rows."""
+        st_ = self.step
+        st = self.side_st if on_side else self.st
+        check(lib.rec_dedup_plan_sorted_slabs_i64(_p(pl["msg_theirs"]), st_.P, st_.cap, st_.rows_per_shard,
+                                                  _p(pl["o_uniq"]), _p(pl["o_seg"]), _p(pl["o_perm"]), _p(pl["o_nu"]),
+                                                  _p(self.o_ws[buf]), self.o_ws_bytes, st),
+              "rec_dedup_plan_sorted_slabs_i64")
 
-    def gather(self, table, ids):
-        m = ids.numel()
-        out = torch.empty((m, 32), dtype=torch.float32, device=table.device)
-        check(lib.rec_emb_gather_f32(_p(table), table.shape[0], 32, 32, _p(ids), m, _p(out), _p(self.step.oob), self.st),
-              "rec_emb_gather_f32")
-        return out
+    def gather(self, table, pl):
+        """Owner-side gather of the 128-byte fused rows for the ids every rank asked for."""
+        st_ = self.step
+        check(lib.rec_emb_gather_lists_f32(_p(table), table.shape[0], 32, 32, _p(pl["msg_theirs"]), st_.P, st_.cap,
+                                           _p(self.rows_out), _p(st_.oob), self.st), "rec_emb_gather_lists_f32")
+        return self.rows_out
 
     def rows_step(self, pl, rows_local, y):
-        """The fused forward+backward kernel on the exchanged rows: the local [n_uniq,32] buffer is the "table" and
-        the ids are the compact indices uidx.  Returns (vals [n,16], gz [B]); the dense gradients follow in
-        local_grad (the reduction shares its launch with the segment sums)."""
+        """The fused forward+backward kernel on the exchanged rows: the local [P*cap,32] buffer is the "table" and
+        the ids are the slots uidx.  Returns (vals [n,16], gz [B]); the dense gradients follow in local_grad (the
+        reduction shares its launch with the segment sums)."""
         st_ = self.step
         L = st_.layer
         check(lib.rec_deepfm_fused_main_f32(
@@ -693,49 +702,29 @@ class HipStepBackend:
 
     def local_grad(self, pl, vals, gz):
         """Reduction of the workgroup partials (fills step.g / step.loss) and, in the same launch, this batch's
-        gradient per unique id as rows [embed 16 | w | 0 0 0] ([n,20]; first n_uniq rows, ascending id = send
-        order)."""
+        gradient per unique id as rows [embed 16 | w | 0 0 0] in the id's slot of the [P*cap,20] send buffer."""
         st_ = self.step
         g = st_.g
-        check(lib.rec_deepfm_fused_post_f32(
+        check(lib.rec_deepfm_fused_post_slots_f32(
             st_.F, st_.B, _p(gz), _p(vals), _p(g["MLP_layer1.kernel_0"]), _p(g["MLP_layer1.bias_0"]),
             _p(g["MLP_layer1.kernel_1"]), _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]),
             _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(st_.loss), _p(self.ws), _p(pl["perm"]), _p(pl["col_uid"]),
-            _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.uniq_ids), _p(self.grows), None, _p(self.n_uniq), 1, self.st),
-            "rec_deepfm_fused_post_f32")
+            _p(pl["col_seg"]), _p(pl["col_nu"]), _p(pl["slot_map"]), _p(self.grows), self.st),
+            "rec_deepfm_fused_post_slots_f32")
         return self.grows
 
-    def _owner_buffers(self, m):
-        if m > self._cap:
-            cap = int(m * 1.25) + 1024
-            dev = self.step.dev
-            self.o_uniq = torch.empty(cap, dtype=torch.int64, device=dev)
-            self.o_seg = torch.empty(cap + 1, dtype=torch.int32, device=dev)
-            self.o_perm = torch.empty(cap, dtype=torch.int32, device=dev)
-            self.o_nu = torch.zeros(1, dtype=torch.int64, device=dev)
-            self.o_rows = torch.empty((cap, 20), dtype=torch.float32, device=dev)
-            self.o_ws_bytes = lib.rec_dedup_workspace_bytes(cap)
-            self.o_ws = torch.empty(self.o_ws_bytes, dtype=torch.uint8, device=dev)
-            self.o_sws = torch.empty(lib.rec_segment_sum_workspace_bytes(cap, 20), dtype=torch.uint8, device=dev)
-            self._cap = cap
-
-    def owner_reduce(self, their_ids, recv_counts, rows_theirs, scale):
-        """Union of the P ascending id lists that arrived + row sums in list order, times ``scale``.
-        Returns (uniq local ids, embed rows [.,16], w rows [.,1] -- views of one [.,20] buffer that the next step
-        overwrites --, n_uniq)."""
-        m = their_ids.numel()
-        self._owner_buffers(m)
+    def owner_reduce(self, pl, rows_theirs, scale):
+        """Row sums in the order of the owner plan, times ``scale``.  Returns (uniq local ids, embed rows [.,16], w rows
+        [.,1] -- views of one [P*cap,20] buffer that the next step overwrites --, n_uniq); entries past n_uniq are
+        padding (a valid id, zero rows)."""
+        m = rows_theirs.shape[0]
         st = self.st
-        check(lib.rec_dedup_plan_sorted_lists_i64(_p(their_ids), m, _p(recv_counts), recv_counts.numel(),
-                                                  self.step.rows_per_shard, _p(self.o_uniq), _p(self.o_seg),
-                                                  _p(self.o_perm), _p(self.o_nu), _p(self.o_ws), self.o_ws_bytes, st),
-              "rec_dedup_plan_sorted_lists_i64")
-        check(lib.rec_segment_sum_f32(_p(rows_theirs), 20, _p(self.o_perm), _p(self.o_seg), m, 1, _p(self.o_rows),
+        check(lib.rec_segment_sum_f32(_p(rows_theirs), 20, _p(pl["o_perm"]), _p(pl["o_seg"]), m, 1, _p(self.o_rows),
                                       _p(self.o_sws), st), "rec_segment_sum_f32")
-        rows = self.o_rows[:m]
+        rows = self.o_rows
         if scale != 1.0:
             check(lib.rec_axpby_f32(scale, _p(rows), 0.0, _p(rows), rows.numel(), st), "rec_axpby_f32")
-        return self.o_uniq[:m], rows[:, :16], rows[:, 16:17], self.o_nu
+        return pl["o_uniq"], rows[:, :16], rows[:, 16:17], pl["o_nu"]
 
     def check_flags(self):
         if int(self.bad_ids.item()) != 0:
@@ -745,19 +734,20 @@ class HipStepBackend:
 class ShardedDeepFMStep:
     """DeepFM train_loop iteration with the fused [embed|w|pad] table ROW-SHARDED over the ranks of a process group
     (SURVEY.md section 8e): data-parallel batch (every rank its own B examples), block partition
-    ``owner = id // ceil(V/P)``.  De-duplicate first, then exchange:
+    ``owner = id // ceil(V/P)``.  De-duplicate first, then exchange -- in FIXED-CAPACITY slabs: the field layout bounds
+    the unique ids one batch can hold for one owner (exchange_capacity), so every exchange has constant split sizes:
+    no count exchange, nothing read back by the host, every buffer allocated once.
 
         plan (ids only; built for batch k+1 on a second stream while batch k is differentiated)
-            per-column sort + unique  ->  the batch's unique ids, ascending = already grouped by owner
-            C0  all-to-all of the per-owner unique-id counts on its OWN communicator (own RCCL stream, so it does not
-                queue behind the payload collectives); both count vectors travel to the host asynchronously
-        C1  all-to-all of the unique local ids                              (RCCL; "nccl" backend on ROCm)
-        --  owner-side gather of the 128-byte fused rows                    (HIP, ids ascending)
-        C2  all-to-all of the rows back -> a local [n_uniq, 32] table in id order: no permutation anywhere
-        --  the fused forward+backward kernel on those rows (it gathers by the compact index of each lookup),
-            then the per-unique-id segment sums of the row gradients (embed 16 + w 1), in send order
-        C3  all-to-all of the summed row gradients (one [.,20] buffer) to the owners, who merge the P ascending
-            lists (rank merge)
+            per-column sort + unique  ->  the batch's unique ids, ascending = already grouped by owner; every owner's
+            ids go to its slab of the id message [P, 2+cap] (word 0 = how many)
+            C1  all-to-all of the id messages on its OWN communicator (own RCCL stream: it does not queue behind
+                the payload collectives), then the owner's union of the P lists that arrived (rank merge)
+        --  owner-side gather of the 128-byte fused rows into [P, cap, 32]     (HIP, ids ascending per list)
+        C2  all-to-all of the rows back -> a local [P*cap, 32] table, row = owner*cap + slot: no permutation anywhere
+        --  the fused forward+backward kernel on those rows (it gathers by the slot of each lookup), then the
+            per-unique-id segment sums of the row gradients (embed 16 + w 1) written to the ids' slots
+        C3  all-to-all of the summed row gradients ([P*cap,20]) to the owners, who add them in the order of the union
         C4  one flat all-reduce (SUM) of the dense gradients and the loss, divided by P
 
     The loss is the mean over the GLOBAL batch of P*B examples (2.FM/ModelManager.py:171-177 on the concatenated
@@ -787,6 +777,7 @@ class ShardedDeepFMStep:
             fused[:, 16:17].copy_(w.data)
         self.V = V
         self.rows_per_shard = -(-V // self.P)
+        self.cap = exchange_capacity(field_dims, field_offsets, B, self.rows_per_shard, self.P)
         lo = min(V, self.rank * self.rows_per_shard)
         hi = min(V, lo + self.rows_per_shard)
         self.row_range = (lo, hi)
@@ -832,13 +823,12 @@ class ShardedDeepFMStep:
             cols.append(c)
         return cols
 
-    def _finish_plan(self, pl, buf):
-        """C0 + the asynchronous hand-over of both split-size vectors to the host."""
-        if pl.get("recv") is not None:
-            self.comm.exchange_counts(pl["counts"], out=pl["recv"])   # preallocated: outlives the stream it is made on
-        else:
-            pl["recv"] = self.comm.exchange_counts(pl["counts"])
-        pl["host"] = self.be.counts_to_host(pl, buf)
+    def _plan(self, cols, buf, on_side):
+        """Plan + C1 + the owner's union of what arrived: everything that depends on the ids alone."""
+        pl = self.be.plan(cols, buf, on_side=on_side)
+        pl["msg_theirs"] = self.comm.exchange_ids(pl["msg"], pl["msg_theirs"])
+        self.be.owner_plan(pl, buf, on_side=on_side)
+        return pl
 
     def __call__(self, inputs, label_name="label", next_inputs=None):
         be, comm = self.be, self.comm
@@ -851,37 +841,56 @@ class ShardedDeepFMStep:
             be.join()                                        # the plan was built on the second stream
         else:
             buf = 0
-            pl = be.plan(cols, buf)
-            self._finish_plan(pl, buf)
+            pl = self._plan(cols, buf, False)
         self._next = None
         if next_inputs is not None:
             next_cols = self._cols(next_inputs)
             be.fork()
-            nxt = be.plan(next_cols, 1 - buf, on_side=True)
-            with be.side_context():
-                self._finish_plan(nxt, 1 - buf)              # C0 of the next batch: own communicator, second stream
+            with be.side_context():                          # C1 of the next batch: own communicator, second stream
+                nxt = self._plan(next_cols, 1 - buf, True)
             self._next = (tuple(c.data_ptr() for c in next_cols), 1 - buf, nxt)
-        send, recv = pl["host"].get()                        # split sizes (on the host a step early when pipelined)
-        nu = sum(send)
-        their_ids = comm.all_to_all(pl["uid_local"][:nu], send, recv)          # C1
-        rows_out = be.gather(self.table_shard, their_ids)                      # owner-side gather of 128-B rows
-        rows_local = comm.all_to_all(rows_out, recv, send)                     # C2: [n_uniq, 32] in ascending id order
+        rows_out = be.gather(self.table_shard, pl)                             # owner-side gather of 128-B rows
+        rows_local = comm.exchange(rows_out, be.rows_local)                    # C2: [P*cap, 32], row = owner*cap + slot
         vals, gz = be.rows_step(pl, rows_local, y)
         grows = be.local_grad(pl, vals, gz)
-        rows_theirs = comm.all_to_all(grows[:nu], send, recv)                  # C3
-        if their_ids.numel():
-            self.table_grad = be.owner_reduce(their_ids, pl["recv"], rows_theirs, 1.0 / self.P)
-        else:
-            self.table_grad = None
+        rows_theirs = comm.exchange(grows, be.rows_theirs)                     # C3
+        self.table_grad = be.owner_reduce(pl, rows_theirs, 1.0 / self.P)
         # C4: dense gradients and the loss, one flat all-reduce (mean over ranks = the global-batch gradient)
         if self.P > 1:
             comm.all_reduce_sum(self.flat)
             self.flat /= self.P
         return self.loss
 
+    def many(self, batches, label_name="label"):
+        """A cycle of steps over resident batches as ONE captured hipGraph (RCCL collectives included: every exchange
+        has constant sizes and nothing is read back, so the sequence is a fixed program).  The plan of the first batch
+        is built inside the graph on the main stream, the plans of the following ones on the second stream beside the
+        step before.  Every rank must call it with the same number of batches.  Returns the loss of the last step."""
+        key = tuple(self._cols(b)[0].data_ptr() for b in batches) + tuple(b[label_name].data_ptr() for b in batches)
+        graphs = self.__dict__.setdefault("_graphs", {})
+        g = graphs.get(key)
+        if g is None:
+            def run():
+                self._next = None
+                for i, b in enumerate(batches):
+                    self(b, label_name, next_inputs=batches[i + 1] if i + 1 < len(batches) else None)
+            run()                                            # communicators and lazy initialisation: not captured
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                run()
+            graphs[key] = g
+        g.replay()
+        return self.loss
+
+    def release_graphs(self):
+        """Drop the captured graphs (before the process group is destroyed: they hold RCCL kernels)."""
+        self.__dict__.pop("_graphs", None)
+
     def check_flags(self):
         if int(self.oob.item()) != 0:
-            raise IndexError("embedding id out of range [0, feature_dims)")
+            raise IndexError("embedding id out of range [0, feature_dims), or more unique ids for one owner than the "
+                             "exchange capacity")
         self.be.check_flags()
 
 

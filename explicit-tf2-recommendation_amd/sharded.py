@@ -71,6 +71,16 @@ class DistComm:
         dist.all_to_all_single(out, x, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
         return out
 
+    def exchange(self, x, out):
+        """Equal-split all-to-all of a [world * k, ...] buffer into a preallocated one (fixed-capacity exchanges)."""
+        dist.all_to_all_single(out, x, group=self.group)
+        return out
+
+    def exchange_ids(self, x, out):
+        """The same on the second communicator (the id messages of the NEXT batch, beside the current step)."""
+        dist.all_to_all_single(out, x, group=self.count_group)
+        return out
+
     def all_reduce_sum(self, x):
         dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
         return x

@@ -217,6 +217,33 @@ int rec_colsort_shard_map_i64(const int32_t* perm, const int64_t* col_uid, const
                               const int32_t* col_nu, int64_t B, int F, int64_t rows_per_shard, int n_shard,
                               int64_t* uid_local, int64_t* uidx, int64_t* send_counts, int64_t* n_uniq,
                               int* oob_flag, void* stream);
+/* The same plan for FIXED-CAPACITY exchanges (constant split sizes: no count exchange, no host read; the whole sharded
+ * step can be captured in a hipGraph).  Every owner has a slab of `cap` slots; cap >= the unique ids one batch can hold
+ * for one owner = sum over the fields that intersect the owner's block of min(B, overlap) (else *oob_flag is set).
+ * msg [n_shard, 2 + cap] int64: word 0 = unique ids for this owner, word 1 = 0, then the owner-local ids, ascending;
+ * uidx [F,B] = owner * cap + j (row of the lookup in the [n_shard * cap, .] buffer the rows come back in);
+ * slot_map [B*F] int32 (first *n_uniq valid): rank in the batch's ascending unique list -> owner * cap + j. */
+int rec_colsort_shard_map_fixed_i64(const int32_t* perm, const int64_t* col_uid, const int32_t* col_seg,
+                                    const int32_t* col_nu, int64_t B, int F, int64_t rows_per_shard, int n_shard,
+                                    int64_t cap, int64_t* msg, int64_t* uidx, int32_t* slot_map, int64_t* n_uniq,
+                                    int* oob_flag, void* stream);
+/* Owner side of it.  Gather for n_lists received slabs (msg layout above): out [n_lists * cap, E], row (q, j) written
+ * only for j < count_q.  E a power of two in [4, 256], 16-byte aligned operands. */
+int rec_emb_gather_lists_f32(const float* table, int64_t V, int E, int64_t ld, const int64_t* msg, int n_lists,
+                             int64_t cap, float* out, int* oob_flag, void* stream);
+/* Union of the n_lists ascending duplicate-free lists of such a message (rank merge, no sort) as a segment plan over
+ * the [n_lists * cap, .] payload rows: uniq_ids [n_lists*cap], seg_start [n_lists*cap + 1], perm [n_lists*cap] (payload
+ * row of every sorted position), *n_uniq; tails padded as rec_dedup_plan_i64 does (valid id, empty runs), so
+ * rec_segment_sum_f32(n = n_lists*cap) follows without a host read.  workspace: rec_dedup_workspace_bytes(n_lists*cap). */
+int rec_dedup_plan_sorted_slabs_i64(const int64_t* msg, int n_lists, int64_t cap, int64_t V, int64_t* uniq_ids,
+                                    int32_t* seg_start, int32_t* perm, int64_t* n_uniq, void* workspace,
+                                    size_t workspace_bytes, void* stream);
+/* Post launch of the fused step for that layout: dense-gradient reduction + per-unique-id sums of (vals, gz) written as
+ * packed rows [embed 16 | w | 0 0 0] to g_rows [n_shard * cap, 20] at slot_map[rank]; unused slots are left alone. */
+int rec_deepfm_fused_post_slots_f32(int F, int64_t B, const float* gz, const float* vals, float* dK0, float* db0,
+                                    float* dK1, float* db1, float* dK2, float* db2, float* dbias, float* loss,
+                                    void* workspace, const int32_t* perm, const int64_t* col_uid, const int32_t* col_seg,
+                                    const int32_t* col_nu, const int32_t* slot_map, float* g_rows, void* stream);
 /* out[perm[i], :] = in[i, :]   (inverse permutation of received rows) and its transpose */
 int rec_permute_rows_f32(const float* in, const int64_t* perm, int64_t n, int E, int scatter, float* out,
                          void* stream);

@@ -109,17 +109,14 @@ def test_oracle_backend_matches_bucketize_contract():
 
 class OracleStepBackend:
     """CPU stand-in for engine.HipStepBackend (TEST ONLY): the oracle plays the device kernels so that the 2-rank
-    exchange logic of ShardedDeepFMStep (unique-first splits, 1/P scaling, flat all-reduce) runs under gloo."""
-
-    class _Now:
-        def __init__(self, send, recv):
-            self.v = (send.tolist(), recv.tolist())
-
-        def get(self):
-            return self.v
+    exchange logic of ShardedDeepFMStep (unique-first fixed-capacity slabs, 1/P scaling, flat all-reduce) runs under
+    gloo."""
 
     def __init__(self, step, field_dims, field_offsets):
         self.step = step
+        m = step.P * step.cap
+        self.rows_local = torch.zeros((m, 32))
+        self.rows_theirs = torch.zeros((m, 20))
 
     def begin(self):
         pass
@@ -136,24 +133,37 @@ class OracleStepBackend:
 
     def plan(self, cols, buf, on_side=False):
         st = self.step
+        P, cap = st.P, st.cap
         X = np.concatenate([c.numpy().reshape(-1, 1) for c in cols], 1)                 # [B,F]
         uid, inv = np.unique(X, return_inverse=True)
         owner = uid // st.rows_per_shard
-        return {"uid_local": torch.from_numpy(uid - owner * st.rows_per_shard),
-                "uidx": torch.from_numpy(inv.reshape(X.shape).T.copy()),                # [F,B]
-                "counts": torch.from_numpy(np.bincount(owner, minlength=st.P).astype(np.int64)),
-                "n_uniq": torch.tensor([len(uid)])}
+        counts = np.bincount(owner, minlength=P)
+        assert counts.max() <= cap                       # exchange_capacity's bound
+        start = np.concatenate([[0], np.cumsum(counts)])
+        slot = owner * cap + (np.arange(len(uid)) - start[owner])
+        msg = np.zeros((P, cap + 2), np.int64)
+        msg[:, 0] = counts
+        msg[owner, 2 + slot - owner * cap] = uid - owner * st.rows_per_shard
+        return {"msg": torch.from_numpy(msg), "msg_theirs": torch.zeros((P, cap + 2), dtype=torch.int64),
+                "uidx": torch.from_numpy(slot[inv.reshape(X.shape)].T.copy()),       # [F,B]
+                "slot_map": torch.from_numpy(slot.astype(np.int32)), "n_uniq": torch.tensor([len(uid)])}
 
-    def counts_to_host(self, pl, buf):
-        return self._Now(pl["counts"], pl["recv"])
+    def owner_plan(self, pl, buf, on_side=False):
+        pass
 
-    def gather(self, table, ids):
-        return OracleBackend.gather(table, ids)
+    def gather(self, table, pl):
+        st = self.step
+        msg = pl["msg_theirs"]
+        out = torch.zeros((st.P * st.cap, 32))
+        for q in range(st.P):
+            c = int(msg[q, 0])
+            out[q * st.cap:q * st.cap + c] = table[msg[q, 2:2 + c]]
+        return out
 
     def rows_step(self, pl, rows_local, y):
         from oracle import torch_ref as T
         st = self.step
-        lay, B, F = st.layer, st.B, st.F
+        lay = st.layer
         rows = rows_local.double().requires_grad_()
         pr = {k: v.detach().double().requires_grad_() for k, v in lay.named_parameters()
               if k not in ("embed.embeddings", "w.embeddings")}
@@ -166,20 +176,23 @@ class OracleStepBackend:
         st.loss.copy_(loss.detach().float().reshape(1))
         for k in st.g:
             st.g[k].copy_(pr[k].grad.float().reshape(st.g[k].shape))
-        self._row_grad = rows.grad                       # already summed per unique id by autograd
+        self._row_grad = rows.grad                       # already summed per slot by autograd
         return None, None
 
     def local_grad(self, pl, vals, gz):
         return self._row_grad[:, :20].float().contiguous()         # [embed 16 | w | pad]: autograd leaves pad = 0
 
-    def owner_reduce(self, their_ids, recv_counts, rows_theirs, scale):
-        c = recv_counts.tolist()
-        o = 0
-        for k in c:                                      # contract of the merge: every list ascending and unique
-            part = their_ids[o:o + k].numpy()
+    def owner_reduce(self, pl, rows_theirs, scale):
+        st = self.step
+        msg = pl["msg_theirs"]
+        ids, rows = [], []
+        for q in range(st.P):                            # contract of the merge: every list ascending and unique
+            c = int(msg[q, 0])
+            part = msg[q, 2:2 + c].numpy()
             assert np.all(part[1:] > part[:-1])
-            o += k
-        u, rows, nu = OracleBackend.dedup_sum(their_ids, rows_theirs, 0)
+            ids.append(msg[q, 2:2 + c])
+            rows.append(rows_theirs[q * st.cap:q * st.cap + c])
+        u, rows, nu = OracleBackend.dedup_sum(torch.cat(ids), torch.cat(rows), 0)
         rows = rows * scale
         return u, rows[:, :16], rows[:, 16:17], nu
 
@@ -343,12 +356,15 @@ def _gpu_step_worker(rank, world, port, V, B, F, result):
             """gloo between two processes that share the ONE GPU of the test box (RCCL refuses two ranks on one
             device): payloads hop through host memory, everything else -- every kernel -- is the product path."""
 
-            def exchange_counts(self, counts, out=None):
-                r = super().exchange_counts(counts.cpu()).cuda()
-                return r if out is None else out.copy_(r)
+            def exchange(self, x, out):
+                torch.cuda.current_stream().synchronize()
+                h = torch.empty(x.shape, dtype=x.dtype)
+                return out.copy_(super().exchange(x.cpu(), h))
 
-            def all_to_all(self, x, in_splits, out_splits):
-                return super().all_to_all(x.cpu(), in_splits, out_splits).cuda()
+            def exchange_ids(self, x, out):
+                torch.cuda.current_stream().synchronize()
+                h = torch.empty(x.shape, dtype=x.dtype)
+                return out.copy_(super().exchange_ids(x.cpu(), h))
 
             def all_reduce_sum(self, x):
                 x.copy_(super().all_reduce_sum(x.cpu()))
