@@ -52,6 +52,35 @@ __device__ __forceinline__ float feat_act(int kind, float x, float alpha, float 
   return y;
 }
 
+// The same inside the attention kernels, where 12 (forward) / 12 x 3 (backward) evaluations per lane and tile made the
+// VALU the busiest unit: hardware exp2 / reciprocal (1 ulp each; scores stay within 1e-6 of the accurate form), the
+// Dice scale 1/sqrt(var + eps) precomputed per unit (rstd).
+__device__ __forceinline__ float sigmoid_hw(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+template <bool GRAD>
+__device__ __forceinline__ float feat_act_hw(int kind, float x, float alpha, float mean, float rstd, float& dydx,
+                                             float& dyda) {
+  float y = x, dx = 1.f, da = 0.f;
+  switch (kind) {
+    case DACT_RELU: y = fmaxf(x, 0.f); dx = x > 0.f ? 1.f : 0.f; break;
+    case DACT_SIGMOID: y = sigmoid_hw(x); dx = y * (1.f - y); break;
+    case DACT_TANH: y = tanhf(x); dx = 1.f - y * y; break;
+    case DACT_DICE: {
+      float p = sigmoid_hw((x - mean) * rstd);
+      float q = 1.f - p;
+      y = alpha * q * x + p * x;
+      if (GRAD) {
+        dx = alpha * q + p + x * (p * q * rstd) * (1.f - alpha);
+        da = q * x;
+      }
+      break;
+    }
+    case DACT_PRELU: y = x > 0.f ? x : alpha * x; dx = x > 0.f ? 1.f : alpha; da = x > 0.f ? 0.f : x; break;
+    default: break;
+  }
+  if (GRAD) { dydx = dx; dyda = da; }
+  return y;
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight preparation: W1 [3D + D*D, H], b1 [H]  ->  Wcat [D, D*H + H] = [Wo_r | W_q + W_d],  Wkd [D,H] = W_k - W_d,
 // bext [D*H + H] = [0 | b1], with Wo_r[j, i*H + o] = W1[3D + i*D + j, o].
@@ -105,17 +134,22 @@ __global__ __launch_bounds__(256) void din_prep_bwd_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// attention forward / backward: one workgroup (4 waves) per example.  The time axis is cut into chunks of TC = 64 steps
-// whose key rows are gathered into LDS (KT, zero-padded); the [T,D] x [D,H] product against Eff_b and, in the backward,
-// gEff = K^T . gpre and gkeys = gpre . Eff^T run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: lane l holds
-// A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; D: col = l&15, row = 4*(l>>4) + reg).  Wave w owns rows 16w..16w+15 of
-// the chunk for everything that is per time step; all dimensions are padded to multiples of 16 with zeros in LDS, so
-// padded rows / columns contribute exact zeros.  Keys are never written to HBM in the forward.
-// LDS (floats): Eff [Dp][HS] | cvec [Hp] | KT [TC][DS] | msb [TC] | maskb [TC] | red [4][Dp]
-//               backward adds: GP [TC][HS] | gsb [TC] | gpl [Dp] | redh [4][4][Hp]
+// attention forward / backward: one workgroup (4 waves) per example, and inside it every WAVE works on its own tiles of
+// 16 time steps (tiles wave, wave + 4, ...) from the gather to the stores: no workgroup barrier inside the time loop, so
+// the gather latency of one wave hides behind the matrix work of the eleven others on the CU.  The tile's key rows sit in
+// a wave-private slab of LDS (zero-padded); pre = K.Eff, gEff = K^T.gpre and gkeys = gpre.Eff^T run on the fp32 matrix
+// cores (v_mfma_f32_16x16x4_f32: lane l holds A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; D: col = l&15, row =
+// 4*(l>>4) + reg).  The contraction index of every product is PERMUTED so that a lane's four k steps are one 16-byte LDS
+// read (k step c of block q is d = 16q + 4g + c for lane group g) or registers it already holds (the D layout of `pre`
+// IS the B layout of K^T.gpre with time step 4g + c as k step c); with row strides = 4 (mod 16) floats every one of those
+// reads and the D-layout writes touch 64 distinct banks.  All dimensions are padded to multiples of 16 with zeros in
+// LDS, so padded rows / columns contribute exact zeros.  Keys are never written to HBM in the forward.
+// LDS (floats): Eff [Dp][HS] | cvec [Hp] | gpl [Dp] | KT [64][DS] | GP [64][HS] | msb, maskb, gsb [64] | red / redh
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int TC = 64;
+constexpr int TW = 16;              // time steps per wave tile
+constexpr int TC = 4 * TW;          // ... per round of the workgroup
+constexpr int NBR = 6;              // 16-byte pieces of key rows a lane holds per tile (16 rows x D <= 96 floats)
 
 struct AttnArgs {
   const float* embed; int64_t ld; int64_t V; int E; int C;
@@ -124,52 +158,51 @@ struct AttnArgs {
   int act; const float* alpha; const float* mean; const float* var;
   const float* w2; const float* b2;
   int64_t padding_index; int mask_valid;
-  int stop;      // diagnostics only (REC_DIN_STOP, scripts/exp/din_{fwd,bwd}_phases.sh): forward 1-4 = leave after that
-                 // phase, backward 12-14 = skip the later steps; 0 = run everything
 };
 
-struct AttnLds {
-  int Dp, Hp, DS, HS;
-  size_t eff, cvec, kt, msb, maskb, red, gp, gsb, gpl, redh, total;   // offsets in floats
+// LDS layout (floats).  Every extent is a compile-time constant (ND = padded D / 16, NT = padded H / 16): the row strides
+// fold into the offset fields of the LDS instructions instead of living in address registers.
+template <int NT, int ND, bool BWD>
+struct AL {
+  static constexpr int Dp = 16 * ND, Hp = 16 * NT;
+  static constexpr int DS = Dp + 4, HS = Hp + 4;           // = 4 (mod 16)
+  static constexpr int eff = 0;
+  static constexpr int cvec = eff + Dp * HS;
+  static constexpr int gpl = cvec + Hp;
+  static constexpr int kt = gpl + Dp;
+  static constexpr int gp = kt + TC * DS;
+  static constexpr int msb = gp + (BWD ? TC * HS : 0);
+  static constexpr int maskb = msb + TC;
+  static constexpr int gsb = maskb + TC;
+  static constexpr int red = gsb + TC;
+  static constexpr int total = red + (BWD ? 16 * Hp : 4 * Dp);
 };
 
-__host__ __device__ inline AttnLds attn_layout(int D, int H, bool bwd) {
-  AttnLds L;
-  L.Dp = (D + 15) & ~15;
-  L.Hp = (H + 15) & ~15;
-  L.DS = L.Dp + 1;
-  L.HS = L.Hp + 1;
-  size_t o = 0;
-  L.eff = o; o += (size_t)L.Dp * L.HS;
-  L.cvec = o; o += L.Hp;
-  L.kt = o; o += (size_t)TC * L.DS;
-  L.msb = o; o += TC;
-  L.maskb = o; o += TC;
-  L.red = o; o += 4 * (size_t)L.Dp;
-  L.gp = o; if (bwd) o += (size_t)TC * L.HS;
-  L.gsb = o; if (bwd) o += TC;
-  L.gpl = o; if (bwd) o += L.Dp;
-  L.redh = o; if (bwd) o += 16 * (size_t)L.Hp;
-  L.total = o;
-  return L;
+// LDS traffic of ONE wave (its own slab): program order inside the wave is enough, the compiler must not reorder
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Eff = Wkd + M_b (zero-padded), c_b; zero the padding columns of KT once
-__device__ __forceinline__ void attn_load_eff(const AttnArgs& a, int64_t b, int D, int H, const AttnLds& L, float* lds) {
-  float* Eff = lds + L.eff;
-  float* cvec = lds + L.cvec;
-  float* KT = lds + L.kt;
+template <class L>
+__device__ __forceinline__ void attn_load_eff(const AttnArgs& a, int64_t b, int D, int H, float* lds) {
+  float* Eff = lds + L::eff;
+  float* cvec = lds + L::cvec;
+  float* KT = lds + L::kt;
   const int64_t NM = (int64_t)D * H + H;
   const float* mrow = a.Mext + b * NM;
   const int DH = D * H;
   if ((DH & 3) == 0 && (NM & 3) == 0 &&
       ((reinterpret_cast<uintptr_t>(a.Mext) | reinterpret_cast<uintptr_t>(a.Wkd)) & 15) == 0) {
     // the row [Eff part D*H | c part H] is streamed as float4 (4 per lane in flight) and scattered into the padded tile
-    for (int i = threadIdx.x; i < L.Dp * L.HS; i += 256) {           // padding entries first (disjoint from the rest)
-      int r = i / L.HS, o = i - r * L.HS;
-      if (r >= D || o >= H) Eff[i] = 0.f;
-    }
-    for (int o = H + threadIdx.x; o < L.Hp; o += 256) cvec[o] = 0.f;
+    // padding entries first (disjoint from the rest): columns H.. of the real rows, then the rows beyond D
+    for (int r = threadIdx.x >> 4; r < D; r += 16)
+      for (int o = H + (threadIdx.x & 15); o < L::HS; o += 16) Eff[r * L::HS + o] = 0.f;
+    for (int i = D * L::HS + threadIdx.x; i < L::Dp * L::HS; i += 256) Eff[i] = 0.f;
+    for (int o = H + threadIdx.x; o < L::Hp; o += 256) cvec[o] = 0.f;
+    const int h_magic = (1 << 20) / H + 1;                 // f / H for f < 2^20 / H (D*H <= 16384)
     const float4* m4 = reinterpret_cast<const float4*>(mrow);
     const float4* w4 = reinterpret_cast<const float4*>(a.Wkd);
     const int n4 = (int)(NM >> 2), dh4 = DH >> 2;
@@ -191,10 +224,10 @@ __device__ __forceinline__ void attn_load_eff(const AttnArgs& a, int64_t b, int 
         float e[4] = {mv[u].x + wv[u].x, mv[u].y + wv[u].y, mv[u].z + wv[u].z, mv[u].w + wv[u].w};
         int f = 4 * i;
         if (i < dh4) {
-          int r = f / H, o = f - r * H;
+          int r = (int)(((uint64_t)(unsigned)f * (unsigned)h_magic) >> 20), o = f - r * H;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            Eff[r * L.HS + o] = e[j];
+            Eff[r * L::HS + o] = e[j];
             if (++o == H) { o = 0; ++r; }
           }
         } else {
@@ -204,7 +237,7 @@ __device__ __forceinline__ void attn_load_eff(const AttnArgs& a, int64_t b, int 
       }
     }
   } else {
-    const int n_eff = L.Dp * L.HS;
+    constexpr int n_eff = L::Dp * L::HS;
     for (int i0 = threadIdx.x; i0 < n_eff; i0 += 256 * 6) {
       float wv[6], mv[6];
 #pragma unroll
@@ -212,7 +245,7 @@ __device__ __forceinline__ void attn_load_eff(const AttnArgs& a, int64_t b, int 
         int i = i0 + u * 256;
         wv[u] = mv[u] = 0.f;
         if (i < n_eff) {
-          int r = i / L.HS, o = i - r * L.HS;
+          int r = i / L::HS, o = i - r * L::HS;
           if (r < D && o < H) { wv[u] = a.Wkd[r * H + o]; mv[u] = mrow[(int64_t)r * H + o]; }
         }
       }
@@ -222,131 +255,179 @@ __device__ __forceinline__ void attn_load_eff(const AttnArgs& a, int64_t b, int 
         if (i < n_eff) Eff[i] = wv[u] + mv[u];
       }
     }
-    for (int o = threadIdx.x; o < L.Hp; o += 256) cvec[o] = o < H ? mrow[(int64_t)DH + o] : 0.f;
+    for (int o = threadIdx.x; o < L::Hp; o += 256) cvec[o] = o < H ? mrow[(int64_t)DH + o] : 0.f;
   }
-  const int padc = L.DS - D;                               // columns D .. DS-1 of every KT row stay zero
-  for (int i = threadIdx.x; i < TC * padc; i += 256) KT[(i / padc) * L.DS + D + i % padc] = 0.f;
+  const int padc = L::DS - D;                              // columns D .. DS-1 of every KT row stay zero
+  for (int i = threadIdx.x; i < TC * padc; i += 256) KT[(i / padc) * L::DS + D + i % padc] = 0.f;
 }
 
-// key rows t0 .. t0+TC-1 -> KT (rows beyond T and rows of out-of-range ids: zeros), mask of every row -> maskb.
-// One lane per 16 bytes of a row, six independent loads per lane issued before the first is consumed: a lane that
-// walked a whole 128-byte row by itself (load, wait, store, eight times) made this phase eight dependent memory round
-// trips per chunk, and with 2-3 workgroups per CU that latency WAS the kernel (forward 160 us at config E).
-__device__ __forceinline__ void attn_gather(const AttnArgs& a, int64_t b, int t0, int D, const AttnLds& L, float* lds,
-                                            bool* bad) {
-  float* KT = lds + L.kt;
-  float* maskb = lds + L.maskb;
+// Key rows t0 .. t0+15 of one wave tile, in two halves so that the rows of the NEXT tile travel while this one is worked
+// on: `issue` starts the loads (ids, then up to NBR independent 16-byte row pieces per lane, 8 lanes = one 128-byte row
+// at E = 32; rows beyond T and rows of out-of-range ids: zeros), `commit` puts them into the wave's slab KTw [16][DS].
+struct RowRegs {
+  float4 v[NBR];
+  int off[NBR];     // LDS offset of the piece inside the slab, -1: this lane has no piece u
+  unsigned okm;     // bit u: piece u is a real row (inside the series, id in range); else it is stored as zeros
+  int64_t mid;      // lanes 0..15: series id (table 0) of row `lane` -- the mask
+  float sc;         // lanes 0..15 (backward): the forward's score of that row
+  bool row_in;      // lanes 0..15: row `lane` lies inside the series
+};
+// Every load is issued unconditionally from a clamped (always valid) address and judged afterwards: a load inside a
+// guarded block is waited for before the next one is issued, which turned the six ids and six row pieces of a tile into
+// twelve dependent memory round trips.
+template <class L>
+__device__ __forceinline__ void attn_rows_issue(const AttnArgs& a, int64_t b, int t0, int lane, int e4_shift,
+                                                int c_magic, const float* scores, RowRegs& R, bool* bad) {
   const int E = a.E, C = a.C;
   const int64_t* ser = a.series + (int64_t)b * a.T * C;
-  for (int row = threadIdx.x; row < TC; row += 256) {
-    int t = t0 + row;
+  const int total = (TW * C) << e4_shift;
+  {
+    const int t = t0 + (lane & (TW - 1));
+    const int tc = t < a.T ? t : a.T - 1;
+    R.row_in = lane < TW && t < a.T;
+    R.mid = ser[(int64_t)tc * C];
+    R.sc = scores ? scores[b * a.T + tc] : 0.f;
+  }
+  int64_t id[NBR];
+  int e4s[NBR];
+  bool live[NBR];
+#pragma unroll
+  for (int u = 0; u < NBR; ++u) {
+    const int i = lane + u * 64;
+    const bool mine = i < total;
+    const int ic = mine ? i : 0;
+    const int rr = ic >> e4_shift, e4 = ic - (rr << e4_shift);   // (row, table) pair and 16-byte piece of its row
+    const int row = (rr * c_magic) >> 16, r = rr - row * C;      // rr / C for rr < 1024 (c_magic = 65536 / C + 1)
+    const int t = t0 + row;
+    R.off[u] = mine ? row * L::DS + r * E + 4 * e4 : -1;
+    e4s[u] = 4 * e4;
+    live[u] = mine && t < a.T;                                   // beyond the series: a zero row, not an error
+    id[u] = ser[(int64_t)(t < a.T ? t : a.T - 1) * C + r];
+  }
+  R.okm = 0u;
+#pragma unroll
+  for (int u = 0; u < NBR; ++u) {
+    const bool inr = (uint64_t)id[u] < (uint64_t)a.V;
+    if (live[u] && !inr) *bad = true;
+    if (live[u] && inr) R.okm |= 1u << u;
+    R.v[u] = *reinterpret_cast<const float4*>(a.embed + (inr ? id[u] : 0) * a.ld + e4s[u]);
+  }
+}
+// mask of row `lane` (lanes 0..15) from the id that came with the rows; reference quirk: mask = (id == padding)
+__device__ __forceinline__ float attn_mask_of(const AttnArgs& a, const RowRegs& R) {
+  if (!R.row_in) return 0.f;
+  const bool pad = R.mid == a.padding_index;
+  return (a.mask_valid ? !pad : pad) ? 1.f : 0.f;
+}
+__device__ __forceinline__ void attn_rows_commit(const RowRegs& R, float* KTw) {
+#pragma unroll
+  for (int u = 0; u < NBR; ++u) {
+    if (R.off[u] >= 0) {
+      const bool ok = (R.okm >> u) & 1u;
+      *reinterpret_cast<float4*>(KTw + R.off[u]) = ok ? R.v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+__device__ __forceinline__ void attn_mask_rows(const AttnArgs& a, int64_t b, int t0, int lane, float* maskw) {
+  if (lane < TW) {
+    const int64_t* ser = a.series + (int64_t)b * a.T * a.C;
+    int t = t0 + lane;
     float m = 0.f;
     if (t < a.T) {
-      bool pad = ser[(int64_t)t * C] == a.padding_index;
-      m = (a.mask_valid ? !pad : pad) ? 1.f : 0.f;           // reference quirk: mask = (id == padding)
+      bool pad = ser[(int64_t)t * a.C] == a.padding_index;
+      m = (a.mask_valid ? !pad : pad) ? 1.f : 0.f;         // reference quirk: mask = (id == padding)
     }
-    maskb[row] = m;
+    maskw[lane] = m;
   }
-  constexpr int NB = 6;
-  if ((E & 3) == 0 && (a.ld & 3) == 0) {
-    const int E4 = E >> 2, total = TC * C * E4;
-    for (int i0 = threadIdx.x; i0 < total; i0 += 256 * NB) {
-      float4 v[NB];
-      int off[NB];
+}
+// any E / ld / D: the tile's rows element by element, loads and stores in rounds of NBR per lane (no prefetch)
+template <class L>
+__device__ __forceinline__ void attn_rows_slow(const AttnArgs& a, int64_t b, int t0, int lane, float* KTw, bool* bad) {
+  const int E = a.E, C = a.C;
+  const int64_t* ser = a.series + (int64_t)b * a.T * C;
+  const int total = TW * C * E;
+  for (int i0 = lane; i0 < total; i0 += 64 * NBR) {
+    float v[NBR];
+    int off[NBR];
 #pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        int i = i0 + u * 256;
-        off[u] = -1;
-        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < total) {
-          int rr = i / E4, e4 = i - rr * E4;
-          int row = rr / C, r = rr - row * C;
-          int t = t0 + row;
-          off[u] = row * L.DS + r * E + 4 * e4;
-          if (t < a.T) {
-            int64_t id = ser[(int64_t)t * C + r];
-            if ((uint64_t)id < (uint64_t)a.V) v[u] = *reinterpret_cast<const float4*>(a.embed + id * a.ld + 4 * e4);
-            else *bad = true;
-          }
+    for (int u = 0; u < NBR; ++u) {
+      int i = i0 + u * 64;
+      off[u] = -1;
+      v[u] = 0.f;
+      if (i < total) {
+        int rr = i / E, e = i - rr * E;
+        int row = rr / C, r = rr - row * C;
+        int t = t0 + row;
+        off[u] = row * L::DS + r * E + e;
+        if (t < a.T) {
+          int64_t id = ser[(int64_t)t * C + r];
+          if ((uint64_t)id < (uint64_t)a.V) v[u] = a.embed[id * a.ld + e];
+          else *bad = true;
         }
       }
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        if (off[u] < 0) continue;
-        float* dst = KT + off[u];
-        dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
-      }
     }
-  } else {
-    const int total = TC * C * E;
-    for (int i0 = threadIdx.x; i0 < total; i0 += 256 * NB) {
-      float v[NB];
-      int off[NB];
 #pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        int i = i0 + u * 256;
-        off[u] = -1;
-        v[u] = 0.f;
-        if (i < total) {
-          int rr = i / E, e = i - rr * E;
-          int row = rr / C, r = rr - row * C;
-          int t = t0 + row;
-          off[u] = row * L.DS + r * E + e;
-          if (t < a.T) {
-            int64_t id = ser[(int64_t)t * C + r];
-            if ((uint64_t)id < (uint64_t)a.V) v[u] = a.embed[id * a.ld + e];
-            else *bad = true;
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < NB; ++u)
-        if (off[u] >= 0) KT[off[u]] = v[u];
-    }
+    for (int u = 0; u < NBR; ++u)
+      if (off[u] >= 0) KTw[off[u]] = v[u];
   }
 }
 
-// pre-activation tile of this wave's 16 rows: acc[n][r] = sum_d KT[r0 + 4g + r][d] * Eff[d][16n + l15]
-template <int NT>
-__device__ __forceinline__ void attn_pre_gemm(const float* KT, const float* Eff, const AttnLds& L, int r0, int l15, int g,
-                                              f32x4 (&acc)[NT]) {
+// pre-activation tile of the wave's 16 rows: acc[n][r] = sum_d KTw[4g + r][d] * Eff[d][16n + l15]; with DOT also
+// dot = sum over this lane's d of gpl[d] * KTw[l15][d] (the caller adds the four lane groups)
+template <class L, int NT, int ND, bool DOT>
+__device__ __forceinline__ void attn_pre_gemm(const float* KTw, const float* Eff, const float* gpl, int l15, int g,
+                                              f32x4 (&acc)[NT], float& dot) {
 #pragma unroll
   for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const float* ap = KT + (r0 + l15) * L.DS + g;
-  const float* bp = Eff + g * L.HS + l15;
-  const int nk = L.Dp >> 2;
-  float ac = ap[0], bc[NT];
+  const float* ap = KTw + l15 * L::DS + 4 * g;
+  const float* bp = Eff + 4 * g * L::HS + l15;
+  const float* gq = gpl + 4 * g;
+#pragma unroll(DOT ? 1 : 2)
+  for (int q = 0; q < ND; ++q) {
+    const float4 a4 = *reinterpret_cast<const float4*>(ap + 16 * q);
+    const float ac[4] = {a4.x, a4.y, a4.z, a4.w};
+    float bc[4][NT];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) bc[n] = bp[16 * n];
-  for (int k = 0; k + 1 < nk; ++k) {
-    float an = ap[4 * (k + 1)], bn[NT];
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) bn[n] = bp[4 * (k + 1) * L.HS + 16 * n];
+      for (int n = 0; n < NT; ++n) bc[c][n] = bp[(16 * q + c) * L::HS + 16 * n];
+    if (DOT) {
+      const float4 gp4 = *reinterpret_cast<const float4*>(gq + 16 * q);
+      dot += (gp4.x * ac[0] + gp4.y * ac[1]) + (gp4.z * ac[2] + gp4.w * ac[3]);
+    }
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac, bc[n], acc[n], 0, 0, 0);
-    ac = an;
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) bc[n] = bn[n];
+      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[c], bc[c][n], acc[n], 0, 0, 0);
   }
-#pragma unroll
-  for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac, bc[n], acc[n], 0, 0, 0);
 }
 
-template <int NT>
-__global__ __launch_bounds__(256) void din_attn_fwd_kernel(AttnArgs a, int D, int H, float* __restrict__ scores,
-                                                           float* __restrict__ pooled, int* oob) {
+template <int NT, int ND>
+__global__ __launch_bounds__(256, 3) void din_attn_fwd_kernel(AttnArgs a, int D, int H, float* __restrict__ scores,
+                                                              float* __restrict__ pooled, int* oob) {
+  using L = AL<NT, ND, false>;
   extern __shared__ float lds[];
-  const AttnLds L = attn_layout(D, H, false);
-  float* Eff = lds + L.eff;
-  float* cvec = lds + L.cvec;
-  float* KT = lds + L.kt;
-  float* msb = lds + L.msb;
-  float* maskb = lds + L.maskb;
-  float* red = lds + L.red;
+  float* Eff = lds + L::eff;
+  float* cvec = lds + L::cvec;
+  float* red = lds + L::red;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l15 = lane & 15, g = lane >> 4, r0 = wave * 16;
+  const int l15 = lane & 15, g = lane >> 4, r0 = wave * TW;
+  float* KTw = lds + L::kt + r0 * L::DS;                    // the wave's slab
+  float* msw = lds + L::msb + r0;
+  float* maskw = lds + L::maskb + r0;
   const int64_t b = blockIdx.x;
-  attn_load_eff(a, b, D, H, L, lds);
+  bool bad = false;
+  // fast rows: 16-byte pieces, at most NBR per lane and tile -> the first two tiles of the wave are requested before
+  // anything else happens, every later one two tiles ahead of its use
+  // fast rows: 16-byte pieces, a power of two of them per row, at most NBR per lane and tile
+  const int e4_shift = 31 - __clz(a.E >> 2 > 0 ? a.E >> 2 : 1), c_magic = 65536 / a.C + 1;
+  const bool fast = (a.E & 3) == 0 && (a.ld & 3) == 0 && (4 << e4_shift) == a.E && TW * a.C * (a.E >> 2) <= 64 * NBR;
+  RowRegs R0, R1;
+  if (fast) {
+    if (r0 < a.T) attn_rows_issue<L>(a, b, r0, lane, e4_shift, c_magic, nullptr, R0, &bad);
+    if (r0 + TC < a.T) attn_rows_issue<L>(a, b, r0 + TC, lane, e4_shift, c_magic, nullptr, R1, &bad);
+  }
+  attn_load_eff<L>(a, b, D, H, lds);
   float al[NT], mu[NT], vr[NT], w2h[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
@@ -354,94 +435,118 @@ __global__ __launch_bounds__(256) void din_attn_fwd_kernel(AttnArgs a, int D, in
     bool ok = h < H;
     al[n] = (ok && a.alpha) ? a.alpha[h] : 0.f;
     mu[n] = (ok && a.mean) ? a.mean[h] : 0.f;
-    vr[n] = (ok && a.var) ? a.var[h] : 1.f;
+    vr[n] = (ok && a.var) ? rsqrtf(a.var[h] + BN_EPS) : 1.f;   // Dice: 1 / sqrt(var + eps)
     w2h[n] = ok ? a.w2[h] : 0.f;                           // padded units contribute nothing to the score
   }
   const float b2 = a.b2[0];
-  float pacc[4] = {0.f, 0.f, 0.f, 0.f};                    // pooled dims lane, lane+64, lane+128, lane+192
-  bool bad = false;
-  if (a.stop == 1) return;
-  for (int t0 = 0; t0 < a.T; t0 += TC) {
-    __syncthreads();                                       // Eff ready / previous chunk consumed
-    attn_gather(a, b, t0, D, L, lds, &bad);
-    __syncthreads();
-    if (a.stop == 2) continue;
-    if (t0 + r0 >= a.T) continue;                          // wave-uniform: all 16 rows of this wave are beyond T (no
-                                                           // barrier below in this iteration, zero contribution)
+  constexpr int NP = (L::Dp + 63) / 64;
+  float pacc[NP];                                          // pooled dims lane, lane+64, ...
+#pragma unroll
+  for (int j = 0; j < NP; ++j) pacc[j] = 0.f;
+  __syncthreads();                                         // Eff, cvec and the zero padding are in place
+
+  auto tile = [&](RowRegs& R, int t0) {
+    wave_lds_sync();                                       // the previous tile has been consumed
+    if (fast) {
+      attn_rows_commit(R, KTw);
+      if (lane < TW) maskw[lane] = attn_mask_of(a, R);
+      if (t0 + 2 * TC < a.T) attn_rows_issue<L>(a, b, t0 + 2 * TC, lane, e4_shift, c_magic, nullptr, R, &bad);
+    } else {
+      attn_rows_slow<L>(a, b, t0, lane, KTw, &bad);
+      attn_mask_rows(a, b, t0, lane, maskw);
+    }
+    wave_lds_sync();
     f32x4 acc[NT];
-    attn_pre_gemm<NT>(KT, Eff, L, r0, l15, g, acc);
-    if (a.stop == 3) { if (acc[0][0] == 12345.f) pacc[0] += 1.f; continue; }
+    float unused = 0.f;
+    attn_pre_gemm<L, NT, ND, false>(KTw, Eff, nullptr, l15, g, acc, unused);
     float sr[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       float cv = cvec[16 * n + l15];
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        sr[r] += feat_act(a.act, acc[n][r] + cv, al[n], mu[n], vr[n], nullptr, nullptr) * w2h[n];
+        sr[r] += feat_act_hw<false>(a.act, acc[n][r] + cv, al[n], mu[n], vr[n], unused, unused) * w2h[n];
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) sr[r] += __shfl_xor(sr[r], o, 64);      // over the 16 unit lanes
-      sr[r] += b2;
-    }
+    for (int r = 0; r < 4; ++r) sr[r] = row16_allsum(sr[r]) + b2;       // over the 16 unit lanes
     if (l15 == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int row = r0 + 4 * g + r, t = t0 + row;
+        int row = 4 * g + r, t = t0 + row;
         if (t < a.T) scores[b * a.T + t] = sr[r];
-        msb[row] = maskb[row] * sr[r];
+        msw[row] = maskw[row] * sr[r];
       }
     }
-    if (a.stop == 4) continue;
-    // masked weighted sum of this wave's 16 key rows (msb of these rows was written by this wave)
+    wave_lds_sync();
+    // masked weighted sum of the tile's 16 key rows
+    float ms[TW];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int q4 = 0; q4 < TW / 4; ++q4) {
+      const float4 m4 = *reinterpret_cast<const float4*>(msw + 4 * q4);
+      ms[4 * q4] = m4.x; ms[4 * q4 + 1] = m4.y; ms[4 * q4 + 2] = m4.z; ms[4 * q4 + 3] = m4.w;
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
       int d = lane + 64 * j;
-      if (d < L.Dp) {
+      if (d < L::Dp) {
         float p = 0.f;
 #pragma unroll
-        for (int row = 0; row < 16; ++row) p += msb[r0 + row] * KT[(r0 + row) * L.DS + d];
+        for (int row = 0; row < TW; ++row) p += ms[row] * KTw[row * L::DS + d];
         pacc[j] += p;
       }
     }
+  };
+#pragma unroll 1
+  for (int t0 = r0; t0 < a.T; t0 += 2 * TC) {
+    tile(R0, t0);
+    if (t0 + TC < a.T) tile(R1, t0 + TC);
   }
   if (bad && oob) *oob = 1;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NP; ++j) {
     int d = lane + 64 * j;
-    if (d < L.Dp) red[wave * L.Dp + d] = pacc[j];
+    if (d < L::Dp) red[wave * L::Dp + d] = pacc[j];
   }
   __syncthreads();
   for (int d = tid; d < D; d += 256)
-    pooled[b * D + d] = ((red[d] + red[L.Dp + d]) + red[2 * L.Dp + d]) + red[3 * L.Dp + d];
+    pooled[b * D + d] = ((red[d] + red[L::Dp + d]) + red[2 * L::Dp + d]) + red[3 * L::Dp + d];
 }
 
-template <int NT>
-__global__ __launch_bounds__(256) void din_attn_bwd_kernel(AttnArgs a, int D, int H, const float* __restrict__ scores,
-                                                           const float* __restrict__ gpooled,
-                                                           float* __restrict__ gkeys /* [B,T,D] */,
-                                                           float* __restrict__ gMext /* [B, D*H+H] */,
-                                                           float* __restrict__ gw2p /* [B,H] */,
-                                                           float* __restrict__ galphap /* [B,H] */,
-                                                           float* __restrict__ gb2p /* [B] */) {
+// NMT: d tiles of gEff a wave accumulates at a time (its 16 time steps x all units); NPASS > 1 (D > 128): several passes
+// over the series, the later ones only for their gEff tiles
+template <int NT, int NMT, int NPASS>
+__global__ __launch_bounds__(256, 2) void din_attn_bwd_kernel(AttnArgs a, int D, int H, const float* __restrict__ scores,
+                                                              const float* __restrict__ gpooled,
+                                                              float* __restrict__ gkeys /* [B,T,D] */,
+                                                              float* __restrict__ gMext /* [B, D*H+H] */,
+                                                              float* __restrict__ gw2p /* [B,H] */,
+                                                              float* __restrict__ galphap /* [B,H] */,
+                                                              float* __restrict__ gb2p /* [B] */) {
+  constexpr int ND = NMT * NPASS;
+  using L = AL<NT, ND, true>;
   extern __shared__ float lds[];
-  const AttnLds L = attn_layout(D, H, true);
-  float* Eff = lds + L.eff;
-  float* cvec = lds + L.cvec;
-  float* KT = lds + L.kt;
-  float* msb = lds + L.msb;
-  float* maskb = lds + L.maskb;
-  float* GP = lds + L.gp;
-  float* gsb = lds + L.gsb;
-  float* gpl = lds + L.gpl;
-  float* redh = lds + L.redh;
+  float* Eff = lds + L::eff;
+  float* cvec = lds + L::cvec;
+  float* gpl = lds + L::gpl;
+  float* redh = lds + L::red;
+  float* GE = lds + L::kt;                                  // [16 * NMT][Hp]: aliases the slabs, behind barriers
+  static_assert(16 * NMT * L::Hp <= TC * (L::DS + L::HS), "gEff staging must fit into the slabs");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l15 = lane & 15, g = lane >> 4, r0 = wave * 16;
+  const int l15 = lane & 15, g = lane >> 4, r0 = wave * TW;
+  float* KTw = lds + L::kt + r0 * L::DS;
+  float* GPw = lds + L::gp + r0 * L::HS;
+  float* msw = lds + L::msb + r0;
+  float* maskw = lds + L::maskb + r0;
+  float* gsw = lds + L::gsb + r0;
   const int64_t b = blockIdx.x;
   const int64_t NM = (int64_t)D * H + H;
-  attn_load_eff(a, b, D, H, L, lds);
-  for (int d = tid; d < L.Dp; d += 256) gpl[d] = d < D ? gpooled[b * D + d] : 0.f;
+  bool bad = false;
+  // fast rows: 16-byte pieces, a power of two of them per row, at most NBR per lane and tile
+  const int e4_shift = 31 - __clz(a.E >> 2 > 0 ? a.E >> 2 : 1), c_magic = 65536 / a.C + 1;
+  const bool fast = (a.E & 3) == 0 && (a.ld & 3) == 0 && (4 << e4_shift) == a.E && TW * a.C * (a.E >> 2) <= 64 * NBR;
+  RowRegs R;
+  attn_load_eff<L>(a, b, D, H, lds);
+  for (int d = tid; d < L::Dp; d += 256) gpl[d] = d < D ? gpooled[b * D + d] : 0.f;
   float al[NT], mu[NT], vr[NT], w2h[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
@@ -449,124 +554,148 @@ __global__ __launch_bounds__(256) void din_attn_bwd_kernel(AttnArgs a, int D, in
     bool ok = h < H;
     al[n] = (ok && a.alpha) ? a.alpha[h] : 0.f;
     mu[n] = (ok && a.mean) ? a.mean[h] : 0.f;
-    vr[n] = (ok && a.var) ? a.var[h] : 1.f;
+    vr[n] = (ok && a.var) ? rsqrtf(a.var[h] + BN_EPS) : 1.f;   // Dice: 1 / sqrt(var + eps)
     w2h[n] = ok ? a.w2[h] : 0.f;
   }
-  // gEff row tiles of this wave: wave, wave + 4, ... (Dp/16 <= 16 tiles)
-  constexpr int MTW = 4;
-  const int nmt = L.Dp >> 4;
-  f32x4 ge[MTW][NT];
-#pragma unroll
-  for (int i = 0; i < MTW; ++i)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) ge[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float gc[NT], gw2a[NT], gala[NT], gb2a = 0.f;
 #pragma unroll
   for (int n = 0; n < NT; ++n) { gc[n] = 0.f; gw2a[n] = 0.f; gala[n] = 0.f; }
-  bool bad = false;
-  for (int t0 = 0; t0 < a.T; t0 += TC) {
-    __syncthreads();
-    attn_gather(a, b, t0, D, L, lds, &bad);
-    __syncthreads();
-    const bool wave_live = t0 + r0 < a.T && a.stop != 12;  // wave-uniform: some of this wave's 16 rows are real steps
-    if (wave_live) {
-    // (1) pre-activations of this wave's rows
-    f32x4 acc[NT];
-    attn_pre_gemm<NT>(KT, Eff, L, r0, l15, g, acc);
-    // (2) d L / d score of row l15 of this wave: mask * <g_pooled, k_t>; (mask*score) kept for the keys' gradient
-    {
+  __syncthreads();                                         // Eff, cvec, gpl and the zero padding are in place
+#pragma unroll 1
+  for (int pass = 0; pass < NPASS; ++pass) {
+    const bool first = pass == 0;
+    const int mt0 = pass * NMT;
+    f32x4 ge[NMT][NT];
+#pragma unroll
+    for (int i = 0; i < NMT; ++i)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) ge[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int t0 = r0; t0 < a.T; t0 += TC) {
+      wave_lds_sync();
+      float m_row = 0.f, sc_row = 0.f;                      // lanes 0..15: mask and forward score of row `lane`
+      if (fast) {
+        attn_rows_issue<L>(a, b, t0, lane, e4_shift, c_magic, scores, R, &bad);
+        attn_rows_commit(R, KTw);
+        m_row = attn_mask_of(a, R);
+        sc_row = R.row_in ? R.sc : 0.f;
+      } else {
+        attn_rows_slow<L>(a, b, t0, lane, KTw, &bad);
+        attn_mask_rows(a, b, t0, lane, maskw);
+      }
+      wave_lds_sync();
+      if (!fast && lane < TW) {
+        m_row = maskw[lane];
+        sc_row = t0 + lane < a.T ? scores[b * a.T + t0 + lane] : 0.f;
+      }
+      // (1) pre-activations of the tile, (2) d L / d score of row l15: mask * <g_pooled, k_t>
+      f32x4 acc[NT];
       float dot = 0.f;
-      const float* kr = KT + (r0 + l15) * L.DS + g;
-#pragma unroll 8
-      for (int j = 0; j < (L.Dp >> 2); ++j) dot += gpl[4 * j + g] * kr[4 * j];
+      attn_pre_gemm<L, NT, ND, true>(KTw, Eff, gpl, l15, g, acc, dot);
       dot += __shfl_xor(dot, 16, 64);
       dot += __shfl_xor(dot, 32, 64);
-      if (g == 0) {
-        int row = r0 + l15, t = t0 + row;
-        float m = maskb[row];
-        gsb[row] = m * dot;
-        msb[row] = t < a.T ? m * scores[b * a.T + t] : 0.f;
+      if (g == 0) {                                        // lanes 0..15 = rows 0..15
+        gsw[l15] = m_row * dot;
+        msw[l15] = m_row * sc_row;                         // (mask*score) for the keys' gradient
       }
-    }
-    float gsr[4];
+      wave_lds_sync();
+      float gsr[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) gsr[r] = gsb[r0 + 4 * g + r];
-    // (3) through the score layer and the activation; gpre tile -> LDS
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      float cv = cvec[16 * n + l15];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float dydx, dyda;
-        float hv = feat_act(a.act, acc[n][r] + cv, al[n], mu[n], vr[n], &dydx, &dyda);
-        float gh = gsr[r] * w2h[n];
-        float gpre = gh * dydx;
-        gw2a[n] += gsr[r] * hv;
-        gala[n] += gh * dyda;
-        gc[n] += gpre;
-        GP[(r0 + 4 * g + r) * L.HS + 16 * n + l15] = gpre;
-      }
-    }
-    if (l15 == 0) gb2a += (gsr[0] + gsr[1]) + (gsr[2] + gsr[3]);
-    }
-    __syncthreads();                                       // GP of the chunk's live rows
-    // (4) gEff += K^T . gpre over the chunk's real steps (groups of 4; rows beyond T inside a group are zero in KT)
-    if (a.stop != 12 && a.stop != 13) {
-      const int live_rows = a.T - t0 < TC ? a.T - t0 : TC;
-      const int nk = (live_rows + 3) >> 2;
-      for (int k = 0; k < nk; ++k) {
-        float bv[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) bv[n] = GP[(4 * k + g) * L.HS + 16 * n + l15];
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) {
-          int mt = wave + 4 * i;
-          if (mt < nmt) {
-            float av = KT[(4 * k + g) * L.DS + 16 * mt + l15];
-#pragma unroll
-            for (int n = 0; n < NT; ++n) ge[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[n], ge[i][n], 0, 0, 0);
-          }
-        }
-      }
-    }
-    // (5) gkeys of this wave's rows: mask*score*g_pooled + gpre . Eff^T
-    if (wave_live && a.stop != 13 && a.stop != 14) {
-      const int nkh = L.Hp >> 2;
-      float msr[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) msr[r] = msb[r0 + 4 * g + r];
-      for (int dt = 0; dt < nmt; ++dt) {
-        f32x4 ak = {0.f, 0.f, 0.f, 0.f};
-        const float* ap = GP + (r0 + l15) * L.HS + g;
-        const float* bp = Eff + (16 * dt + l15) * L.HS + g;
-#pragma unroll 4
-        for (int k = 0; k < nkh; ++k) ak = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * k], bp[4 * k], ak, 0, 0, 0);
-        int d = 16 * dt + l15;
-        if (d < D) {
-          float gp_d = gpl[d];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            int t = t0 + r0 + 4 * g + r;
-            if (t < a.T) gkeys[((int64_t)b * a.T + t) * D + d] = msr[r] * gp_d + ak[r];
-          }
-        }
-      }
-    }
-  }
-  // gEff -> gMext[b, d*H + h]
-#pragma unroll
-  for (int i = 0; i < MTW; ++i) {
-    int mt = wave + 4 * i;
-    if (mt < nmt) {
+      for (int r = 0; r < 4; ++r) gsr[r] = gsw[4 * g + r];
+      // (3) through the score layer and the activation: gpre stays in acc (the B operand of (4)) and goes to the
+      // wave's GP slab (the A operand of (5) needs it with the time step on the other lane index)
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        int h = 16 * n + l15;
+        float cv = cvec[16 * n + l15];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          int d = 16 * mt + 4 * g + r;
-          if (d < D && h < H) gMext[b * NM + (int64_t)d * H + h] = ge[i][n][r];
+          float dydx, dyda;
+          float hv = feat_act_hw<true>(a.act, acc[n][r] + cv, al[n], mu[n], vr[n], dydx, dyda);
+          float gh = gsr[r] * w2h[n];
+          float gpre = gh * dydx;
+          if (first) {
+            gw2a[n] += gsr[r] * hv;
+            gala[n] += gh * dyda;
+            gc[n] += gpre;
+            GPw[(4 * g + r) * L::HS + 16 * n + l15] = gpre;
+          }
+          acc[n][r] = gpre;
         }
       }
+      if (first && l15 == 0) gb2a += (gsr[0] + gsr[1]) + (gsr[2] + gsr[3]);
+      wave_lds_sync();
+      // (4) gEff[d][h] += sum over the tile's steps of K[t][d] * gpre[t][h]; k step c = time step 4g + c
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float* kr = KTw + (4 * g + c) * L::DS + 16 * mt0 + l15;
+#pragma unroll
+        for (int i = 0; i < NMT; ++i) {
+          const float av = kr[16 * i];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) ge[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, acc[n][c], ge[i][n], 0, 0, 0);
+        }
+      }
+      // (5) gkeys of the tile's rows: mask*score*g_pooled + gpre . Eff^T; k step c of block p = unit 16p + 4g + c
+      if (first) {
+        float4 ga[NT];
+#pragma unroll
+        for (int p = 0; p < NT; ++p) ga[p] = *reinterpret_cast<const float4*>(GPw + l15 * L::HS + 16 * p + 4 * g);
+        float msr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) msr[r] = msw[4 * g + r];
+        float* gk = gkeys + ((int64_t)b * a.T + t0 + 4 * g) * D + l15;
+#pragma unroll 1
+        for (int dt = 0; dt < ND; ++dt) {
+          f32x4 ak = {0.f, 0.f, 0.f, 0.f};
+          const float* bp = Eff + (16 * dt + l15) * L::HS + 4 * g;
+#pragma unroll
+          for (int p = 0; p < NT; ++p) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bp + 16 * p);
+            ak = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[p].x, b4.x, ak, 0, 0, 0);
+            ak = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[p].y, b4.y, ak, 0, 0, 0);
+            ak = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[p].z, b4.z, ak, 0, 0, 0);
+            ak = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[p].w, b4.w, ak, 0, 0, 0);
+          }
+          const int d = 16 * dt + l15;
+          if (d < D) {
+            const float gp_d = gpl[d];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (t0 + 4 * g + r < a.T) gk[(int64_t)r * D + 16 * dt] = msr[r] * gp_d + ak[r];
+          }
+        }
+      }
+    }
+    // gEff of this pass: the four waves' partial tiles are added in wave order through LDS, then the rows leave as one
+    // contiguous block of gMext[b, d*H + h]
+    __syncthreads();                                       // every wave is done with its slabs
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int i = 0; i < NMT; ++i)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float* p = GE + (16 * i + 4 * g + r) * L::Hp + 16 * n + l15;
+              *p = (w == 0 ? 0.f : *p) + ge[i][n][r];
+            }
+      }
+      __syncthreads();
+    }
+    {
+      const int d_lo = 16 * mt0;
+      const int rows = (D - d_lo < 16 * NMT) ? D - d_lo : 16 * NMT;
+      float* dst = gMext + b * NM + (int64_t)d_lo * H;
+      for (int dl = wave; dl < rows; dl += 4)
+        for (int h = lane; h < H; h += 64) dst[dl * H + h] = GE[dl * L::Hp + h];
+    }
+    __syncthreads();                                       // GE consumed before the slabs are written again
+    if (pass + 1 < NPASS) {                                 // the alias clobbered the zero padding of the key slabs
+      float* KT = lds + L::kt;
+      const int padc = L::DS - D;
+      for (int i = tid; i < TC * padc; i += 256) KT[(i / padc) * L::DS + D + i % padc] = 0.f;
+      __syncthreads();
     }
   }
   // per-unit sums: over the row groups of the wave (lanes g), then over the waves in a fixed order
@@ -578,31 +707,30 @@ __global__ __launch_bounds__(256) void din_attn_bwd_kernel(AttnArgs a, int D, in
   }
   gb2a += __shfl_xor(gb2a, 16, 64);
   gb2a += __shfl_xor(gb2a, 32, 64);
-  __syncthreads();
   if (g == 0) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       int h = 16 * n + l15;
-      redh[(wave * 4 + 0) * L.Hp + h] = gc[n];
-      redh[(wave * 4 + 1) * L.Hp + h] = gw2a[n];
-      redh[(wave * 4 + 2) * L.Hp + h] = gala[n];
+      redh[(wave * 4 + 0) * L::Hp + h] = gc[n];
+      redh[(wave * 4 + 1) * L::Hp + h] = gw2a[n];
+      redh[(wave * 4 + 2) * L::Hp + h] = gala[n];
     }
-    if (l15 == 0) redh[(wave * 4 + 3) * L.Hp] = gb2a;
+    if (l15 == 0) redh[(wave * 4 + 3) * L::Hp] = gb2a;
   }
   __syncthreads();
   if (tid < H) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     for (int wv = 0; wv < 4; ++wv) {
-      s0 += redh[(wv * 4 + 0) * L.Hp + tid];
-      s1 += redh[(wv * 4 + 1) * L.Hp + tid];
-      s2 += redh[(wv * 4 + 2) * L.Hp + tid];
+      s0 += redh[(wv * 4 + 0) * L::Hp + tid];
+      s1 += redh[(wv * 4 + 1) * L::Hp + tid];
+      s2 += redh[(wv * 4 + 2) * L::Hp + tid];
     }
     gMext[b * NM + (int64_t)D * H + tid] = s0;
     gw2p[b * H + tid] = s1;
     galphap[b * H + tid] = s2;
   }
   if (tid == 0)
-    gb2p[b] = ((redh[3 * L.Hp] + redh[(4 + 3) * L.Hp]) + redh[(8 + 3) * L.Hp]) + redh[(12 + 3) * L.Hp];
+    gb2p[b] = ((redh[3 * L::Hp] + redh[(4 + 3) * L::Hp]) + redh[(8 + 3) * L::Hp]) + redh[(12 + 3) * L::Hp];
   (void)bad;
 }
 
@@ -741,8 +869,6 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   for (int n = lane; n < N; n += 64) gx[row * N + n] = y[row * N + n] * (gy[row * N + n] - s);
 }
 
-size_t attn_lds_bytes(int D, int H, bool bwd) { return attn_layout(D, H, bwd).total * sizeof(float); }
-
 bool attn_args_ok(int D, int H, int E, int C, int T) {
   return D > 0 && H > 0 && E > 0 && C > 0 && T > 0 && D == E * C && H <= 64 && D <= 256;
 }
@@ -768,6 +894,31 @@ extern "C" int rec_din_prepare_bwd_f32(const float* gWcat, const float* gWkd, in
   return REC_OK;
 }
 
+// padded-D classes (ND = padded D / 16): 2, 6, 8 (one pass of the backward) and 16 (two passes of 8 tiles)
+template <int NT, int ND>
+static int launch_attn_fwd(const AttnArgs& a, int64_t B, int D, int H, float* scores, float* pooled, int* oob,
+                           hipStream_t st) {
+  constexpr size_t lds = sizeof(float) * AL<NT, ND, false>::total;
+  if constexpr (lds > 150 * 1024) return REC_E_UNSUPPORTED;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_fwd_kernel<NT, ND>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((din_attn_fwd_kernel<NT, ND>), dim3((unsigned)B), dim3(256), lds, st, a, D, H, scores, pooled, oob);
+  return REC_OK;
+}
+template <int NT, int NMT, int NPASS>
+static int launch_attn_bwd(const AttnArgs& a, int64_t B, int D, int H, const float* scores, const float* gpooled,
+                           float* gkeys, float* gMext, float* gw2p, float* galphap, float* gb2p, hipStream_t st) {
+  constexpr size_t lds = sizeof(float) * AL<NT, NMT * NPASS, true>::total;
+  if constexpr (lds > 150 * 1024) return REC_E_UNSUPPORTED;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_bwd_kernel<NT, NMT, NPASS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((din_attn_bwd_kernel<NT, NMT, NPASS>), dim3((unsigned)B), dim3(256), lds, st, a, D, H, scores,
+                     gpooled, gkeys, gMext, gw2p, galphap, gb2p);
+  return REC_OK;
+}
+
 extern "C" int rec_din_attn_fwd_f32(const float* embed, int64_t ld, int64_t V, int E, int C, const int64_t* series,
                                     int64_t B, int T, const float* Mext, const float* Wkd, int H, int act,
                                     const float* alpha, const float* mean, const float* var, const float* w2,
@@ -779,29 +930,23 @@ extern "C" int rec_din_attn_fwd_f32(const float* embed, int64_t ld, int64_t V, i
   if (B == 0) return REC_OK;
   if (!embed || !series || !Mext || !Wkd || !w2 || !b2 || !scores || !pooled) return REC_E_ARG;
   if ((act == DACT_DICE && (!alpha || !mean || !var)) || (act == DACT_PRELU && !alpha)) return REC_E_ARG;
-  size_t lds = attn_lds_bytes(D, H, false);
-  if (lds > 150 * 1024) return REC_E_UNSUPPORTED;
-#ifdef REC_DEBUG_PHASE_STOPS   // profiling builds only (scripts/exp/*_phases.sh): the kernel stops after phase N
-  static const int din_stop = getenv("REC_DIN_STOP") ? atoi(getenv("REC_DIN_STOP")) : 0;
-#else
-  constexpr int din_stop = 0;
-#endif
-  AttnArgs a{embed, ld, V, E, C, series, T, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index, mask_valid, din_stop};
-#define LAUNCH_FWD(NT)                                                                                            \
-  do {                                                                                                            \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_fwd_kernel<NT>),                   \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
-    if (e != hipSuccess) return (int)e;                                                                           \
-    hipLaunchKernelGGL(din_attn_fwd_kernel<NT>, dim3((unsigned)B), dim3(256), lds, as_stream(stream), a, D, H,    \
-                       scores, pooled, oob_flag);                                                                 \
-  } while (0)
+  AttnArgs a{embed, ld, V, E, C, series, T, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index, mask_valid};
+  hipStream_t st = as_stream(stream);
+  const int nd = (D + 15) / 16;
+  int rc;
+#define FWD_ND(NT)                                                                                     \
+  (nd <= 2 ? launch_attn_fwd<NT, 2>(a, B, D, H, scores, pooled, oob_flag, st)                           \
+   : nd <= 6 ? launch_attn_fwd<NT, 6>(a, B, D, H, scores, pooled, oob_flag, st)                         \
+   : nd <= 8 ? launch_attn_fwd<NT, 8>(a, B, D, H, scores, pooled, oob_flag, st)                         \
+             : launch_attn_fwd<NT, 16>(a, B, D, H, scores, pooled, oob_flag, st))
   switch ((H + 15) / 16) {
-    case 1: LAUNCH_FWD(1); break;
-    case 2: LAUNCH_FWD(2); break;
-    case 3: LAUNCH_FWD(3); break;
-    default: LAUNCH_FWD(4); break;
+    case 1: rc = FWD_ND(1); break;
+    case 2: rc = FWD_ND(2); break;
+    case 3: rc = FWD_ND(3); break;
+    default: rc = FWD_ND(4); break;
   }
-#undef LAUNCH_FWD
+#undef FWD_ND
+  if (rc != REC_OK) return rc;
   REC_LAUNCH_CHECK();
   return REC_OK;
 }
@@ -819,29 +964,23 @@ extern "C" int rec_din_attn_bwd_f32(const float* embed, int64_t ld, int64_t V, i
   if (!embed || !series || !Mext || !Wkd || !w2 || !b2 || !scores || !gpooled || !gkeys || !gMext || !gw2p ||
       !galphap || !gb2p)
     return REC_E_ARG;
-  size_t lds = attn_lds_bytes(D, H, true);
-  if (lds > 150 * 1024) return REC_E_UNSUPPORTED;
-#ifdef REC_DEBUG_PHASE_STOPS   // profiling builds only (scripts/exp/*_phases.sh): the kernel stops after phase N
-  static const int din_stop = getenv("REC_DIN_STOP") ? atoi(getenv("REC_DIN_STOP")) : 0;
-#else
-  constexpr int din_stop = 0;
-#endif
-  AttnArgs a{embed, ld, V, E, C, series, T, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index, mask_valid, din_stop};
-#define LAUNCH_BWD(NT)                                                                                            \
-  do {                                                                                                            \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(din_attn_bwd_kernel<NT>),                   \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
-    if (e != hipSuccess) return (int)e;                                                                           \
-    hipLaunchKernelGGL(din_attn_bwd_kernel<NT>, dim3((unsigned)B), dim3(256), lds, as_stream(stream), a, D, H,    \
-                       scores, gpooled, gkeys, gMext, gw2p, galphap, gb2p);                                       \
-  } while (0)
+  AttnArgs a{embed, ld, V, E, C, series, T, Mext, Wkd, act, alpha, mean, var, w2, b2, padding_index, mask_valid};
+  hipStream_t st = as_stream(stream);
+  const int nd = (D + 15) / 16;
+  int rc;
+#define BWD_ND(NT)                                                                                                   \
+  (nd <= 2 ? launch_attn_bwd<NT, 2, 1>(a, B, D, H, scores, gpooled, gkeys, gMext, gw2p, galphap, gb2p, st)            \
+   : nd <= 6 ? launch_attn_bwd<NT, 6, 1>(a, B, D, H, scores, gpooled, gkeys, gMext, gw2p, galphap, gb2p, st)          \
+   : nd <= 8 ? launch_attn_bwd<NT, 8, 1>(a, B, D, H, scores, gpooled, gkeys, gMext, gw2p, galphap, gb2p, st)          \
+             : launch_attn_bwd<NT, 8, 2>(a, B, D, H, scores, gpooled, gkeys, gMext, gw2p, galphap, gb2p, st))
   switch ((H + 15) / 16) {
-    case 1: LAUNCH_BWD(1); break;
-    case 2: LAUNCH_BWD(2); break;
-    case 3: LAUNCH_BWD(3); break;
-    default: LAUNCH_BWD(4); break;
+    case 1: rc = BWD_ND(1); break;
+    case 2: rc = BWD_ND(2); break;
+    case 3: rc = BWD_ND(3); break;
+    default: rc = BWD_ND(4); break;
   }
-#undef LAUNCH_BWD
+#undef BWD_ND
+  if (rc != REC_OK) return rc;
   REC_LAUNCH_CHECK();
   return REC_OK;
 }
