@@ -42,7 +42,9 @@ def parse():
     ap.add_argument("--resident", type=int, default=16,
                     help="distinct batches resident in HBM and cycled through (16 x 27 MB of table rows > the 256 MB "
                          "memory-side cache: no step finds its rows cached from the previous cycle)")
-    ap.add_argument("--cycle", type=int, default=4, help="steps per captured hipGraph (<= 8; must divide --resident)")
+    ap.add_argument("--cycle", type=int, default=0,
+                    help="steps per captured hipGraph (<= 8; must divide --resident); default: 8 when it divides "
+                         "--steps (fewer graph launches), else 4")
     ap.add_argument("--step-graphs", action="store_true", help="one hipGraph per step instead of one per 4-step cycle")
     ap.add_argument("--sharded-graph", action="store_true",
                     help="row-sharded step: capture each cycle of steps, RCCL collectives included, in one hipGraph "
@@ -172,7 +174,7 @@ def main():
                                       mlp_dims=CFG["mlp_dims"]).cuda()
     gen = data.SyntheticGenerator(names, V, dist=args.dist, seed=rank)
     n_batches = args.resident
-    Cy = args.cycle
+    Cy = args.cycle or (8 if args.steps % 8 == 0 else 4)
     if n_batches % Cy or Cy > 8:
         raise SystemExit("--cycle must divide --resident and be <= 8")
     batches = [data.to_device(gen.batch(B)) for _ in range(n_batches)]
@@ -203,17 +205,25 @@ def main():
     # launch costs ~20 us of idle GPU); --step-graphs keeps one graph per step
     cycle = (not sharded_mode) and (not args.generic) and (not args.no_graph) and (not args.step_graphs)
 
+    def calls_of(n):
+        """The calls of one run of n steps, each with the batches it announces as next: every run starts at batch 0, so
+        its last call announces the first batches of the next run (an input pipeline that knows what comes next) and
+        all runs of the same n are identical -- the rehearsals below capture exactly the graphs the timed run replays."""
+        seq = lambda i: [batches[(i + j) % n_batches] for j in range(min(Cy, n - i))]
+        out, i = [], 0
+        while i < n:
+            cur = seq(i)
+            nxt = seq(i + len(cur)) if i + len(cur) < n else seq(0)
+            out.append((cur, nxt))
+            i += len(cur)
+        return out
+
     def run_steps(n):
         i = 0
         if cycle:       # every call announces the batches of the NEXT call: their plans are built beside this call's steps
-            while n - i >= Cy:
-                b0 = i % n_batches
-                step.many(batches[b0:b0 + Cy], then=[batches[(b0 + Cy + j) % n_batches] for j in range(Cy)])
-                i += Cy
-            if n - i > 0:                                        # ragged tail: one shorter graph
-                b0 = i % n_batches
-                step.many(batches[b0:b0 + n - i], then=[batches[(b0 + n - i + j) % n_batches] for j in range(Cy)])
-                i = n
+            for cur, nxt in calls_of(n):
+                step.many(cur, then=nxt)
+            return
         if sharded_mode and args.sharded_graph:
             while n - i >= Cy:
                 b0 = i % n_batches
@@ -228,16 +238,17 @@ def main():
     # a failure of the row-sharded exchange is a failure of the run: no silent switch to replicas (ask for
     # --replicas explicitly to measure those)
     run_steps(nw)
-    if cycle and args.steps % n_batches:
-        # a ragged K leaves the plan-buffer ring in another state than a whole number of cycles: rehearse the timed
-        # sequence itself (untimed, twice: the ring has two halves) so that no graph is captured inside the timed region
-        run_steps(args.steps)
-        run_steps(args.steps)
     # A full CPython garbage collection walks every tracked object of the imported modules (~45 ms with torch loaded):
     # collect now and keep the collector off inside the timed region (the loop allocates a few tuples per call).
     import gc
     gc.collect()
     gc.disable()
+    # The last untimed steps are the timed sequence itself, twice (the plan-buffer ring has two halves), enqueued right
+    # before the opening barrier: (1) no graph is captured inside the timed region whatever K is; (2) the GPU goes into it
+    # busy -- after an idle stretch (the 45-ms collection above is one) the first ~150 us of work run at idle clocks,
+    # which at K = 20 is a tenth of the region.
+    run_steps(args.steps)
+    run_steps(args.steps)
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps)
@@ -265,18 +276,18 @@ def main():
         rstep = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, optimizer=None, use_graph=not args.no_graph)
 
         def rrun(n):
-            i = 0
-            while (not args.no_graph) and n - i >= Cy:
-                b0 = i % n_batches
-                rstep.many(batches[b0:b0 + Cy], then=[batches[(b0 + Cy + j) % n_batches] for j in range(Cy)])
-                i += Cy
-            while i < n:
+            if not args.no_graph:
+                for cur, nxt in calls_of(n):
+                    rstep.many(cur, then=nxt)
+                return
+            for i in range(n):
                 rstep(batches[i % n_batches], next_inputs=batches[(i + 1) % n_batches])
-                i += 1
 
         rrun(nw)
         gc.collect()
         gc.disable()
+        rrun(args.steps)
+        rrun(args.steps)
         barrier()
         t0 = time.perf_counter()
         rrun(args.steps)

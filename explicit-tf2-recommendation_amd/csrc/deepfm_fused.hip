@@ -642,7 +642,7 @@ struct ColSortArgs {
 constexpr int OW_T = 1024, OW_W = OW_T / 64, OW_BINS = 128, OW_DB = 7;
 
 template <int KPT>
-__global__ __launch_bounds__(OW_T) void colsort_onewg_kernel(Cols cols, const int64_t* __restrict__ col_lo, ColSortArgs a) {
+__global__ __launch_bounds__(OW_T, KPT <= 8 ? 8 : 4) void colsort_onewg_kernel(Cols cols, const int64_t* __restrict__ col_lo, ColSortArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t owl[];
   constexpr int NW = OW_T * KPT;                       // padded word count
   uint32_t* words = owl;                               // [NW]

@@ -617,6 +617,16 @@ class HipStepBackend:
         self.sort_ws = [torch.empty(lib.rec_colsort_workspace_bytes(B, F), dtype=torch.uint8, device=dev)
                         for _ in range(2)]
         self.o_ws = [torch.empty(self.o_ws_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        # every pointer below is fixed for the life of the step: the ctypes argument tuples are built once
+        for buf, pl in enumerate(self.plans):
+            pl["a_sort"] = (_p(self.col_lo), self.max_key, _p(pl["perm"]), _p(pl["col_uid"]), _p(pl["col_seg"]),
+                            _p(pl["col_nu"]), _p(self.bad_ids), _p(self.sort_ws[buf]))
+            pl["a_map"] = (_p(pl["perm"]), _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), B, F,
+                           step.rows_per_shard, P, cap, _p(pl["msg"]), _p(pl["uidx"]), _p(pl["slot_map"]),
+                           _p(pl["n_uniq"]), _p(step.oob))
+            pl["a_owner"] = (P, cap, step.rows_per_shard, _p(pl["o_uniq"]), _p(pl["o_seg"]), _p(pl["o_perm"]),
+                             _p(pl["o_nu"]), _p(self.o_ws[buf]), self.o_ws_bytes)
+            pl["a_plan4"] = (_p(pl["perm"]), _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), _p(pl["slot_map"]))
         self.gz = torch.empty(B, **f32)
         self.vals = torch.empty((n, 16), **f32)
         self.rows_out = torch.zeros((m, 32), **f32)        # owner-side gather result           -> C2
@@ -662,22 +672,15 @@ class HipStepBackend:
         B, F = st_.B, st_.F
         pl = self.plans[buf]
         st = self.side_st if on_side else self.st
-        check(lib.rec_colsort_plan_i64(self._col_arr(cols), F, B, st_.V, _p(self.col_lo), self.max_key, _p(pl["perm"]),
-                                       _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.bad_ids),
-                                       _p(self.sort_ws[buf]), st), "rec_colsort_plan_i64")
-        check(lib.rec_colsort_shard_map_fixed_i64(_p(pl["perm"]), _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]),
-                                                  B, F, st_.rows_per_shard, st_.P, st_.cap, _p(pl["msg"]),
-                                                  _p(pl["uidx"]), _p(pl["slot_map"]), _p(pl["n_uniq"]), _p(st_.oob), st),
-              "rec_colsort_shard_map_fixed_i64")
+        check(lib.rec_colsort_plan_i64(self._col_arr(cols), F, B, st_.V, *pl["a_sort"], st), "rec_colsort_plan_i64")
+        check(lib.rec_colsort_shard_map_fixed_i64(*pl["a_map"], st), "rec_colsort_shard_map_fixed_i64")
         return pl
 
     def owner_plan(self, pl, buf, on_side=False):
         """Union of the P ascending id lists that arrived (rank merge) as a segment plan over the payload rows."""
         st_ = self.step
         st = self.side_st if on_side else self.st
-        check(lib.rec_dedup_plan_sorted_slabs_i64(_p(pl["msg_theirs"]), st_.P, st_.cap, st_.rows_per_shard,
-                                                  _p(pl["o_uniq"]), _p(pl["o_seg"]), _p(pl["o_perm"]), _p(pl["o_nu"]),
-                                                  _p(self.o_ws[buf]), self.o_ws_bytes, st),
+        check(lib.rec_dedup_plan_sorted_slabs_i64(_p(pl["msg_theirs"]), *pl["a_owner"], st),
               "rec_dedup_plan_sorted_slabs_i64")
 
     def gather(self, table, pl):
@@ -692,25 +695,29 @@ class HipStepBackend:
         the ids are the slots uidx.  Returns (vals [n,16], gz [B]); the dense gradients follow in local_grad (the
         reduction shares its launch with the segment sums)."""
         st_ = self.step
-        L = st_.layer
-        check(lib.rec_deepfm_fused_main_f32(
-            _p(rows_local), 32, rows_local.shape[0], pl["uidx_arr"], st_.F, st_.B, _p(L.bias),
-            _p(L.MLP_layer1.kernel_0), _p(L.MLP_layer1.bias_0), _p(L.MLP_layer1.kernel_1), _p(L.MLP_layer1.bias_1),
-            _p(L.MLP_layer2.kernel_0), _p(L.MLP_layer2.bias_0), _p(y), _p(self.gz), _p(self.vals), None, _p(st_.oob),
-            _p(self.ws), self.st), "rec_deepfm_fused_main_f32")
+        w = self.__dict__.get("_a_weights")
+        if w is None:                                        # parameters are updated in place: their addresses stay
+            L = st_.layer
+            w = self._a_weights = (_p(L.bias), _p(L.MLP_layer1.kernel_0), _p(L.MLP_layer1.bias_0),
+                                   _p(L.MLP_layer1.kernel_1), _p(L.MLP_layer1.bias_1), _p(L.MLP_layer2.kernel_0),
+                                   _p(L.MLP_layer2.bias_0))
+            self._a_tail = (_p(self.gz), _p(self.vals), None, _p(st_.oob), _p(self.ws))
+        check(lib.rec_deepfm_fused_main_f32(_p(rows_local), 32, rows_local.shape[0], pl["uidx_arr"], st_.F, st_.B, *w,
+                                            _p(y), *self._a_tail, self.st), "rec_deepfm_fused_main_f32")
         return self.vals, self.gz
 
     def local_grad(self, pl, vals, gz):
         """Reduction of the workgroup partials (fills step.g / step.loss) and, in the same launch, this batch's
         gradient per unique id as rows [embed 16 | w | 0 0 0] in the id's slot of the [P*cap,20] send buffer."""
         st_ = self.step
-        g = st_.g
-        check(lib.rec_deepfm_fused_post_slots_f32(
-            st_.F, st_.B, _p(gz), _p(vals), _p(g["MLP_layer1.kernel_0"]), _p(g["MLP_layer1.bias_0"]),
-            _p(g["MLP_layer1.kernel_1"]), _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]),
-            _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(st_.loss), _p(self.ws), _p(pl["perm"]), _p(pl["col_uid"]),
-            _p(pl["col_seg"]), _p(pl["col_nu"]), _p(pl["slot_map"]), _p(self.grows), self.st),
-            "rec_deepfm_fused_post_slots_f32")
+        a = self.__dict__.get("_a_post")
+        if a is None:
+            g = st_.g
+            a = self._a_post = (_p(g["MLP_layer1.kernel_0"]), _p(g["MLP_layer1.bias_0"]), _p(g["MLP_layer1.kernel_1"]),
+                                _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]), _p(g["MLP_layer2.bias_0"]),
+                                _p(g["bias"]), _p(st_.loss), _p(self.ws))
+        check(lib.rec_deepfm_fused_post_slots_f32(st_.F, st_.B, _p(gz), _p(vals), *a, *pl["a_plan4"], _p(self.grows),
+                                                  self.st), "rec_deepfm_fused_post_slots_f32")
         return self.grows
 
     def owner_reduce(self, pl, rows_theirs, scale):
@@ -823,6 +830,18 @@ class ShardedDeepFMStep:
             cols.append(c)
         return cols
 
+    def _cols_key(self, inputs):
+        """(columns, their addresses) of a batch; validated once per batch dict (the host is the bottleneck of the eager
+        step: 26 dtype / size / stride checks per call were a tenth of it)."""
+        cache = self.__dict__.setdefault("_col_cache", {})
+        ent = cache.get(id(inputs))
+        if ent is None or ent[2] is not inputs:
+            cols = self._cols(inputs)
+            if len(cache) > 256:
+                cache.clear()
+            ent = cache[id(inputs)] = (cols, tuple(c.data_ptr() for c in cols), inputs)
+        return ent[0], ent[1]
+
     def _plan(self, cols, buf, on_side):
         """Plan + C1 + the owner's union of what arrived: everything that depends on the ids alone."""
         pl = self.be.plan(cols, buf, on_side=on_side)
@@ -833,9 +852,8 @@ class ShardedDeepFMStep:
     def __call__(self, inputs, label_name="label", next_inputs=None):
         be, comm = self.be, self.comm
         be.begin()
-        cols = self._cols(inputs)
+        cols, key = self._cols_key(inputs)
         y = inputs[label_name]
-        key = tuple(c.data_ptr() for c in cols)
         if self._next is not None and self._next[0] == key:
             _, buf, pl = self._next
             be.join()                                        # the plan was built on the second stream
@@ -844,11 +862,11 @@ class ShardedDeepFMStep:
             pl = self._plan(cols, buf, False)
         self._next = None
         if next_inputs is not None:
-            next_cols = self._cols(next_inputs)
+            next_cols, next_key = self._cols_key(next_inputs)
             be.fork()
             with be.side_context():                          # C1 of the next batch: own communicator, second stream
                 nxt = self._plan(next_cols, 1 - buf, True)
-            self._next = (tuple(c.data_ptr() for c in next_cols), 1 - buf, nxt)
+            self._next = (next_key, 1 - buf, nxt)
         rows_out = be.gather(self.table_shard, pl)                             # owner-side gather of 128-B rows
         rows_local = comm.exchange(rows_out, be.rows_local)                    # C2: [P*cap, 32], row = owner*cap + slot
         vals, gz = be.rows_step(pl, rows_local, y)
