@@ -60,3 +60,12 @@ for idle, pre in ((0, 0), (0, 0), (0.05, 0), (0.05, 0), (0.05, 16), (0.05, 16), 
     print("K=20 idle %.2f s prespin %2d: %.2f us/step" % (idle, pre, region(20, idle, pre)), flush=True)
 for idle, pre in ((0, 0), (0.05, 0), (0.05, 64)):
     print("K=200 idle %.2f s prespin %2d: %.2f us/step" % (idle, pre, region(200, idle, pre)), flush=True)
+
+import cProfile, pstats
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+run(400)
+pr.disable()
+torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("tottime").print_stats(14)
