@@ -275,7 +275,19 @@ __global__ __launch_bounds__(PMt * 8) void gemm_f32_panel_kernel(int64_t M, int6
                                                                  const float* __restrict__ e0, int64_t lde0,
                                                                  const float* __restrict__ e1, int64_t lde1,
                                                                  float* __restrict__ aux, int64_t kchunk,
-                                                                 float* __restrict__ ws) {
+                                                                 float* __restrict__ ws, int64_t ncp) {
+  // column panels (ncp > 0: a short-K product whose N exceeds one panel, e.g. DIN's q.Wcat with K = 96, N = 3492):
+  // blockIdx.z takes columns [z*ncp, z*ncp + ncp) -- everything column-indexed moves, the A panel is read again
+  if (ncp > 0) {
+    const int64_t n_off = (int64_t)blockIdx.z * ncp;
+    B += TB ? n_off * ldb : n_off;
+    C += n_off;
+    if (bias) bias += n_off;
+    if (e0) e0 += n_off;
+    if (e1) e1 += n_off;
+    if (aux) aux += n_off;
+    N = N - n_off < ncp ? N - n_off : ncp;
+  }
   // split-K (weight gradient H^T.X: M = N = D, K = batch): blockIdx.y takes k in [kb, kb + K) and leaves its partial in
   // ws[blockIdx.y]; splitk_reduce_kernel adds the slices in order.  Inside the kernel K and the operand pointers are
   // those of the slice.
@@ -596,12 +608,17 @@ extern "C" int rec_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
   // row panels x all N: a tall product with a modest N and row-major A (CrossNet matrix mode and its dX, split_k = 1), or
   // its weight gradient H^T.X (A k-major, M and N modest, K = batch): there the panels are multiplied by K slices so
   // that every CU gets one workgroup, and the slices are added in order
-  const bool panel_fwd = !transA && split_k == 1 && N > 64 && N <= PNB * 32 && M >= 64 * 128;
+  // ... or a wider N in several column panels when K is short (the A panel is then cheap to read once per column panel)
+  const int64_t ncol_panels = N <= PNB * 32 ? 1 : ceil_div64(N, PNB * 32);
+  const int64_t ncp = ncol_panels == 1 ? 0 : ((ceil_div64(N, ncol_panels) + 31) / 32) * 32;
+  const bool panel_fwd = !transA && split_k == 1 && N > 64 &&
+                         ((ncol_panels == 1 && M >= 64 * 128) ||
+                          (ncol_panels > 1 && ncol_panels <= 64 && K <= 256 && ceil_div64(M, 64) * ncol_panels >= 192));
   // (measured and not taken: M = N = 835, K = 16384 as 14 panels x 19 K slices ran 456 us against 358 us on the 128x128
   // split-K tiles -- every slice's 2.9 MB of X is fetched by the L2 of each of the 8 XCDs its 14 panels land on)
   const bool panel_wg = false;
   if (panel_fwd || panel_wg) {
-    const int maxb = (int)ceil_div64(ceil_div64(N, 32), 4);            // column blocks per wave, 1..7
+    const int maxb = (int)ceil_div64(ceil_div64(ncp > 0 ? ncp : N, 32), 4);   // column blocks per wave, 1..7
     constexpr int PMt = 64, PKt = 16;
     const size_t lds = sizeof(float) * (2 * PKt * (PMt + PPAD) + 2 * PKt * ((size_t)maxb * 128 + PPAD));
     const int64_t panels = ceil_div64(M, PMt);
@@ -617,14 +634,14 @@ extern "C" int rec_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
         pws = workspace;
       }
     }
-    dim3 grid((unsigned)panels, (unsigned)psplit);
+    dim3 grid((unsigned)panels, (unsigned)psplit, (unsigned)ncol_panels);
 #define PANEL(TAv, TBv, MB)                                                                                          \
   do {                                                                                                               \
     hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_panel_kernel<TAv, TBv, MB, PMt, PKt>), \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
     if (e_ != hipSuccess) return (int)e_;                                                                            \
     hipLaunchKernelGGL((gemm_f32_panel_kernel<TAv, TBv, MB, PMt, PKt>), grid, dim3(PMt * 8), lds, st, M, N, K, A, lda, \
-                       B, ldb, C, ldc, epilogue_kind, bias, e0, lde0, e1, lde1, aux, pchunk, pws);                   \
+                       B, ldb, C, ldc, epilogue_kind, bias, e0, lde0, e1, lde1, aux, pchunk, pws, ncp);              \
   } while (0)
 #define PANEL_MB(TAv, TBv)                                                                                           \
   switch (maxb) {                                                                                                    \

@@ -47,6 +47,33 @@ def grad_np(p):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# E: the short-K, wide-N product in front of the DIN attention (q.Wcat + bext: row panels x several column panels)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,tb", [(4096, 3492, 96, 0), (4096, 3492, 96, 1), (3000, 1001, 200, 0), (2048, 5000, 33, 1)])
+def test_short_k_wide_n_gemm_in_column_panels(R, M, N, K, tb):
+    ops = R.ops
+    r = H.rng(M + N + K)
+    A = r.normal(size=(M, K)).astype(np.float32)
+    Bm = r.normal(0, 0.1, size=(N, K) if tb else (K, N)).astype(np.float32)
+    b = r.normal(size=(N,)).astype(np.float32)
+    E1 = r.normal(size=(M, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ (Bm.astype(np.float64).T if tb else Bm.astype(np.float64))
+    tol = 2e-6 * np.sqrt(K) * max(1.0, np.abs(ref).max())
+    Ad, Bd, bd, E1d = dev(A), dev(Bm), dev(b), dev(E1)
+    C = ops.gemm(Ad, Bd, transB=bool(tb)).cpu().numpy()
+    assert np.abs(C - ref).max() <= tol
+    C = ops.gemm(Ad, Bd, transB=bool(tb), epi=ops.EPI_BIAS, bias=bd).cpu().numpy()
+    assert np.abs(C - (ref + b)).max() <= tol
+    C = ops.gemm(Ad, Bd, transB=bool(tb), epi=ops.EPI_BIAS_RELU, bias=bd).cpu().numpy()
+    assert np.abs(C - np.maximum(ref + b, 0)).max() <= tol
+    C = ops.gemm(Ad, Bd, transB=bool(tb), epi=ops.EPI_ADD, e1=E1d).cpu().numpy()
+    assert np.abs(C - (ref + E1)).max() <= tol
+    wide = torch.full((M, N + 5), 7.0, device="cuda")                 # strided output: columns beyond N stay untouched
+    ops.gemm(Ad, Bd, transB=bool(tb), epi=ops.EPI_BIAS, bias=bd, out=wide[:, :N])
+    assert np.abs(wide[:, :N].cpu().numpy() - (ref + b)).max() <= tol and torch.all(wide[:, N:] == 7.0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # C: the GEMMs of MatrixCrossLayer at config size
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("D", [323, 835])
