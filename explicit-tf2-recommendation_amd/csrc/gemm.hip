@@ -176,8 +176,8 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_big_kernel(int64_t M, int64_t
                                                            const float* __restrict__ bias, const float* __restrict__ e0,
                                                            int64_t lde0, const float* __restrict__ e1, int64_t lde1,
                                                            int64_t kchunk, float* __restrict__ ws, float* __restrict__ aux) {
-  __shared__ float As[LK][LM + LPAD];
-  __shared__ float Bs[LK][LN + LPAD];
+  __shared__ __attribute__((aligned(16))) float As[LK][LM + LPAD];
+  __shared__ __attribute__((aligned(16))) float Bs[LK][LN + LPAD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t m0 = (int64_t)blockIdx.x * LM, n0 = (int64_t)blockIdx.y * LN;
@@ -192,27 +192,59 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_big_kernel(int64_t M, int64_t
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   constexpr int PER = (LM * LK) / 256;   // 8 elements of each operand per thread and K-tile
+  constexpr int PER4 = PER / 4;          // ... as 16-byte pieces when the operand is k-major in memory
   float ra[PER], rb[PER];
+  // A k-major operand (A with TA = 1: A[k][m]; B with TB = 0: B[k][n]) is fetched as 16-byte pieces along its
+  // contiguous index -- 4-byte aligned, the rows of a [*, 835] matrix start anywhere -- and staged with one 16-byte LDS
+  // store: a quarter of the load and store instructions of the element-wise path, which remains for the pieces that
+  // straddle the edge of the matrix or of the K range.  (H^T.X at D = 835: 358 -> see DESIGN.md section 5.)
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  auto fetch_kmajor = [&](const float* __restrict__ P, int64_t ld, int64_t x0, int64_t X, int64_t k0, float* r) {
+#pragma unroll
+    for (int i = 0; i < PER4; ++i) {
+      const int e = tid + i * 256;
+      const int k = e / (LM / 4), x = 4 * (e % (LM / 4));
+      const int64_t gx = x0 + x, gk = k0 + k;
+      if (gx + 3 < X && gk < k_end) {
+        const f32x4u v = *reinterpret_cast<const f32x4u*>(P + gk * ld + gx);
+        r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) r[4 * i + c] = (gx + c < X && gk < k_end) ? P[gk * ld + gx + c] : 0.f;
+      }
+    }
+  };
   auto fetch = [&](int64_t k0) {
+    if (TA == 1) fetch_kmajor(A, lda, m0, M, k0, ra);
+    if (TB == 0) fetch_kmajor(B, ldb, n0, N, k0, rb);
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       int e = tid + i * 256;
-      int m, k;
-      if (TA == 0) { m = e / LK; k = e % LK; } else { k = e / LM; m = e % LM; }
-      int64_t gm = m0 + m, gk = k0 + k;
-      ra[i] = (gm < M && gk < k_end) ? ((TA == 0) ? A[gm * lda + gk] : A[gk * lda + gm]) : 0.f;
-      int n, k2;
-      if (TB == 0) { k2 = e / LN; n = e % LN; } else { n = e / LK; k2 = e % LK; }
-      int64_t gn = n0 + n, gk2 = k0 + k2;
-      rb[i] = (gn < N && gk2 < k_end) ? ((TB == 0) ? B[gk2 * ldb + gn] : B[gn * ldb + gk2]) : 0.f;
+      if (TA == 0) {
+        int m = e / LK, k = e % LK;
+        int64_t gm = m0 + m, gk = k0 + k;
+        ra[i] = (gm < M && gk < k_end) ? A[gm * lda + gk] : 0.f;
+      }
+      if (TB == 1) {
+        int n = e / LK, k2 = e % LK;
+        int64_t gn = n0 + n, gk2 = k0 + k2;
+        rb[i] = (gn < N && gk2 < k_end) ? B[gn * ldb + gk2] : 0.f;
+      }
     }
   };
   auto stage = [&]() {
 #pragma unroll
+    for (int i = 0; i < PER4; ++i) {
+      const int e = tid + i * 256;
+      const int k = e / (LM / 4), x = 4 * (e % (LM / 4));
+      if (TA == 1) *reinterpret_cast<float4*>(&As[k][x]) = make_float4(ra[4 * i], ra[4 * i + 1], ra[4 * i + 2], ra[4 * i + 3]);
+      if (TB == 0) *reinterpret_cast<float4*>(&Bs[k][x]) = make_float4(rb[4 * i], rb[4 * i + 1], rb[4 * i + 2], rb[4 * i + 3]);
+    }
+#pragma unroll
     for (int i = 0; i < PER; ++i) {
       int e = tid + i * 256;
-      if (TA == 0) As[e % LK][e / LK] = ra[i]; else As[e / LM][e % LM] = ra[i];
-      if (TB == 0) Bs[e / LN][e % LN] = rb[i]; else Bs[e % LK][e / LK] = rb[i];
+      if (TA == 0) As[e % LK][e / LK] = ra[i];
+      if (TB == 1) Bs[e % LK][e / LK] = rb[i];
     }
   };
 

@@ -218,15 +218,19 @@ def copy_cols(src, dst_view):
 
 
 def split_k_for(K, M, N, transA=False, transB=False):
-    """Heuristic split of a reduction over the batch so that ~768 workgroups run.  The 64x64 kernel spends ~2 us per
-    16-deep k step (no prefetch), so a few-tile weight gradient [M,N] = X^T dY with K = batch is cut down to 64-deep
-    slices (M=192, N=64, K=8192: 41 -> ~10 us); the partials are added in slice order by the split-K reduce."""
+    """Heuristic split of a reduction over the batch.  The tile kernels keep up to three workgroups per CU, and the time of
+    a few-tile weight gradient [M,N] = X^T dY with K = batch is a staircase in tiles x slices: it is best just below a
+    multiple of the 256 CUs (measured, M = N = 835, K = 16384, 49 tiles: 8 slices 324 us, 10: 265, 12: 313, 15: 260,
+    21: 300; M = N = 323, 9 tiles: 24 slices 79 us, 56: 64, 57: 77).  So: the largest number of slices that keeps
+    tiles x slices <= 768 (512 for very few tiles, whose partials are cheap to add either way), at least 64 k per slice
+    and at most 64 MB of partials; these are added in slice order by the split-K reduce."""
     t = 128 if (M > 64 and N > 64) else 64          # tile edge the kernel will use
     tiles = ((M + t - 1) // t) * ((N + t - 1) // t)
     if tiles >= 512 or K < 1024:
         return 1
-    split = max(1, min(256, -(-768 // max(tiles, 1)), K // 64))
-    cap = max(8, (16 << 20) // max(1, 4 * M * N))       # the partials are written and read again: at most 16 MB of them
+    slots = 512 if tiles < 16 else 768
+    split = max(1, min(256, slots // max(tiles, 1), K // 64))
+    cap = max(8, (64 << 20) // max(1, 4 * M * N))       # the partials are written and read again
     return int(min(split, cap))
 
 
