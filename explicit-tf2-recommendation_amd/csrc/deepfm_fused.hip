@@ -68,6 +68,8 @@ struct FusedArgs {
   float* g_embed;             // [B*F,16] de-duplicated row sums
   float* g_w;                 // [B*F]    ... of the first-order table
   int64_t* uniq_ids;          // [B*F]    the id of every slot
+  int ld;                     // row stride of `table` in floats; anything but 32 only in the plan-after form (the rows
+                              // a sharded step received: [embed 16 | w | pad 3] = 80 bytes on the wire, not 128)
 #ifdef REC_FUSED_STAMPS
   unsigned long long* stamps; // diagnostic build only: [nwg][8 waves][12] s_memrealtime ticks (10 ns)
 #endif
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(512) void deepfm_fwd_bwd_kernel(Cols cols, FusedArg
         bad |= live && !inr;
         ok[i][g] = live && inr;
         const int64_t row = ok[i][g] ? idr[i][g] : 0;
-        v[i][g] = *reinterpret_cast<const float4*>(a.table + row * LD + 4 * cc);
+        v[i][g] = *reinterpret_cast<const float4*>(a.table + row * (DIRECT ? LD : a.ld) + 4 * cc);
       }
     }
     // K0 slice of the owned fields as B fragments of the 32x32x2 product: step s of field i multiplies the row's dims
@@ -1085,7 +1087,8 @@ static int launch_fused(const float* table, int64_t ld, int64_t V, const int64_t
                         float* loss, int* oob_flag, void* workspace, void* stream, const ColSegArgs* seg,
                         bool main_only = false, const DirectArgs* direct = nullptr) {
   if (B <= 0 || F <= 0 || V <= 0) return REC_E_ARG;
-  if (ld != LD || F > 28 || F > REC_MAX_COLS || V >= (int64_t(1) << 31)) return REC_E_UNSUPPORTED;
+  if (F > 28 || F > REC_MAX_COLS || V >= (int64_t(1) << 31)) return REC_E_UNSUPPORTED;
+  if (direct ? ld != LD : (ld < 20 || (ld & 3) != 0)) return REC_E_UNSUPPORTED;
   if (!table || !cols_host || !bias || !K0 || !b0 || !K1 || !b1 || !K2 || !b2 || !label || !gz || !vals || !dK0 ||
       !db0 || !dK1 || !db1 || !dK2 || !db2 || !dbias || !loss || !workspace)
     return REC_E_ARG;
@@ -1107,11 +1110,11 @@ static int launch_fused(const float* table, int64_t ld, int64_t V, const int64_t
   g_fused_stamps = stamps;
   FusedArgs a{table, V, bias, K0, b0, K1, b1, K2, b2, label, B, F, gz, vals, prob, dK0part, small, oob_flag,
               direct ? direct->dloc : nullptr, direct ? direct->col_nu : nullptr, direct ? direct->g_embed : nullptr,
-              direct ? direct->g_w : nullptr, direct ? direct->uniq_ids : nullptr, stamps};
+              direct ? direct->g_w : nullptr, direct ? direct->uniq_ids : nullptr, (int)ld, stamps};
 #else
   FusedArgs a{table, V, bias, K0, b0, K1, b1, K2, b2, label, B, F, gz, vals, prob, dK0part, small, oob_flag,
               direct ? direct->dloc : nullptr, direct ? direct->col_nu : nullptr, direct ? direct->g_embed : nullptr,
-              direct ? direct->g_w : nullptr, direct ? direct->uniq_ids : nullptr};
+              direct ? direct->g_w : nullptr, direct ? direct->uniq_ids : nullptr, (int)ld};
 #endif
   if (direct) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(deepfm_fwd_bwd_kernel<true>),

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 template <int LPR, int UNR>
 __global__ __launch_bounds__(256) void gather_lists_kernel(const float* __restrict__ table, int64_t V, int64_t ld,
                                                            const int64_t* __restrict__ msg, int64_t cap, int hdr,
-                                                           int64_t n, float4* __restrict__ out, int* oob) {
+                                                           int64_t n, float4* __restrict__ out, int* oob, int nc) {
   constexpr int R = 256 / LPR;
   const int c = threadIdx.x & (LPR - 1), rs = threadIdx.x / LPR;
   const int64_t r0 = (int64_t)blockIdx.x * (R * UNR) + rs;
@@ -133,13 +133,13 @@ __global__ __launch_bounds__(256) void gather_lists_kernel(const float* __restri
     const bool ok = (uint64_t)id[j] < (uint64_t)V;
     bad |= used[j] && !ok;
     v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok) v[j] = *reinterpret_cast<const float4*>(table + id[j] * ld + 4 * c);
+    if (ok && c < nc) v[j] = *reinterpret_cast<const float4*>(table + id[j] * ld + 4 * c);
   }
   if (bad && oob) *oob = 1;
 #pragma unroll
-  for (int j = 0; j < UNR; ++j) {
+  for (int j = 0; j < UNR; ++j) {                      // rows of nc 16-byte pieces (nc = LPR: the whole row)
     const int64_t r = r0 + (int64_t)j * R;
-    if (used[j]) out[r * LPR + c] = v[j];
+    if (used[j] && c < nc) out[r * nc + c] = v[j];
   }
 }
 
@@ -201,15 +201,16 @@ extern "C" int rec_emb_gather_f32(const float* table, int64_t V, int E, int64_t 
 extern "C" int rec_emb_gather_lists_f32(const float* table, int64_t V, int E, int64_t ld, const int64_t* msg,
                                         int n_lists, int64_t cap, float* out, int* oob_flag, void* stream) {
   if (V <= 0 || E <= 0 || ld < E || n_lists <= 0 || cap <= 0 || !table || !msg || !out) return REC_E_ARG;
-  if (!(vec4_ok(table, E, ld) && vec4_ok(out, E, E) && (E & (E - 1)) == 0 && E >= 4 && E <= 256))
-    return REC_E_UNSUPPORTED;
-  const int lpr = E / 4;
+  if (!(vec4_ok(table, E, ld) && vec4_ok(out, E, E) && E >= 4 && E <= 256)) return REC_E_UNSUPPORTED;
+  const int nc = E / 4;                                // 16-byte pieces copied per row (rows of E floats in `out`)
+  int lpr = 1;
+  while (lpr < nc) lpr *= 2;                           // lanes per row: the next power of two
   constexpr int UNR = 4;
   const int64_t n = (int64_t)n_lists * cap;
   const unsigned grid = (unsigned)ceil_div64(n, (256 / lpr) * UNR);
 #define GATHER_LISTS(L)                                                                                            \
   hipLaunchKernelGGL((gather_lists_kernel<L, UNR>), dim3(grid), dim3(256), 0, as_stream(stream), table, V, ld, msg, cap, \
-                     2, n, (float4*)out, oob_flag)
+                     2, n, (float4*)out, oob_flag, nc)
   switch (lpr) {
     case 1: GATHER_LISTS(1); break;
     case 2: GATHER_LISTS(2); break;

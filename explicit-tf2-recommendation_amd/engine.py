@@ -652,8 +652,9 @@ class HipStepBackend:
             pl["a_plan4"] = (_p(pl["perm"]), _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), _p(pl["slot_map"]))
         self.gz = torch.empty(B, **f32)
         self.vals = torch.empty((n, 16), **f32)
-        self.rows_out = torch.zeros((m, 32), **f32)        # owner-side gather result           -> C2
-        self.rows_local = torch.zeros((m, 32), **f32)      # C2 ->  the batch's rows, [owner, slot]
+        # rows travel as [embed 16 | w | pad 3] = 80 bytes, not as the 128-byte lines they are stored in (C2 -37 %)
+        self.rows_out = torch.zeros((m, 20), **f32)        # owner-side gather result           -> C2
+        self.rows_local = torch.zeros((m, 20), **f32)      # C2 ->  the batch's rows, [owner, slot]
         self.grows = torch.zeros((m, 20), **f32)           # [embed 16 | w | pad 3] per unique id -> C3
         self.rows_theirs = torch.zeros((m, 20), **f32)     # C3 ->
         self.o_rows = torch.empty((m, 20), **f32)
@@ -709,7 +710,7 @@ class HipStepBackend:
     def gather(self, table, pl):
         """Owner-side gather of the 128-byte fused rows for the ids every rank asked for."""
         st_ = self.step
-        check(lib.rec_emb_gather_lists_f32(_p(table), table.shape[0], 32, 32, _p(pl["msg_theirs"]), st_.P, st_.cap,
+        check(lib.rec_emb_gather_lists_f32(_p(table), table.shape[0], 20, 32, _p(pl["msg_theirs"]), st_.P, st_.cap,
                                            _p(self.rows_out), _p(st_.oob), self.st), "rec_emb_gather_lists_f32")
         return self.rows_out
 
@@ -725,7 +726,7 @@ class HipStepBackend:
                                    _p(L.MLP_layer1.kernel_1), _p(L.MLP_layer1.bias_1), _p(L.MLP_layer2.kernel_0),
                                    _p(L.MLP_layer2.bias_0))
             self._a_tail = (_p(self.gz), _p(self.vals), None, _p(st_.oob), _p(self.ws))
-        check(lib.rec_deepfm_fused_main_f32(_p(rows_local), 32, rows_local.shape[0], pl["uidx_arr"], st_.F, st_.B, *w,
+        check(lib.rec_deepfm_fused_main_f32(_p(rows_local), 20, rows_local.shape[0], pl["uidx_arr"], st_.F, st_.B, *w,
                                             _p(y), *self._a_tail, self.st), "rec_deepfm_fused_main_f32")
         return self.vals, self.gz
 
@@ -773,8 +774,8 @@ class ShardedDeepFMStep:
             ids go to its slab of the id message [P, 2+cap] (word 0 = how many)
             C1  all-to-all of the id messages on its OWN communicator (own RCCL stream: it does not queue behind
                 the payload collectives), then the owner's union of the P lists that arrived (rank merge)
-        --  owner-side gather of the 128-byte fused rows into [P, cap, 32]     (HIP, ids ascending per list)
-        C2  all-to-all of the rows back -> a local [P*cap, 32] table, row = owner*cap + slot: no permutation anywhere
+        --  owner-side gather of the fused rows' 80 used bytes into [P, cap, 20] (HIP, ids ascending per list)
+        C2  all-to-all of the rows back -> a local [P*cap, 20] table, row = owner*cap + slot: no permutation anywhere
         --  the fused forward+backward kernel on those rows (it gathers by the slot of each lookup), then the
             per-unique-id segment sums of the row gradients (embed 16 + w 1) written to the ids' slots
         C3  all-to-all of the summed row gradients ([P*cap,20]) to the owners, who add them in the order of the union

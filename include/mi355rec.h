@@ -228,7 +228,8 @@ int rec_colsort_shard_map_fixed_i64(const int32_t* perm, const int64_t* col_uid,
                                     int64_t cap, int64_t* msg, int64_t* uidx, int32_t* slot_map, int64_t* n_uniq,
                                     int* oob_flag, void* stream);
 /* Owner side of it.  Gather for n_lists received slabs (msg layout above): out [n_lists * cap, E], row (q, j) written
- * only for j < count_q.  E a power of two in [4, 256], 16-byte aligned operands. */
+ * only for j < count_q = the first E floats of the table row (E a multiple of 4 up to 256, E <= ld; the sharded
+ * DeepFM step sends E = 20 of the 32 floats of a fused row: [embed 16 | w | pad]); 16-byte aligned operands. */
 int rec_emb_gather_lists_f32(const float* table, int64_t V, int E, int64_t ld, const int64_t* msg, int n_lists,
                              int64_t cap, float* out, int* oob_flag, void* stream);
 /* Union of the n_lists ascending duplicate-free lists of such a message (rank merge, no sort) as a segment plan over
@@ -272,7 +273,9 @@ int rec_deepfm_fused_step_f32(const float* table, int64_t ld, int64_t V, const i
                               const int32_t* col_nu, int64_t* uniq_ids, float* g_embed_rows, float* g_w_rows,
                               int64_t* n_uniq, int packed, void* stream);
 /* The two halves of rec_deepfm_fused_step_f32 as separate calls (fused kernel | reduction + segment sums): a caller
- * that builds the plan on another stream puts its wait between them, so that only the second half depends on it. */
+ * that builds the plan on another stream puts its wait between them, so that only the second half depends on it.
+ * These plan-after forms take any row stride ld >= 20 that is a multiple of 4 (rows [embed 16 | w | ...]: 32 for a
+ * table, 20 for the rows a sharded step received); the direct-mode form below needs ld = 32. */
 int rec_deepfm_fused_main_f32(const float* table, int64_t ld, int64_t V, const int64_t* const* cols_host, int F,
                               int64_t B, const float* bias, const float* K0, const float* b0, const float* K1,
                               const float* b1, const float* K2, const float* b2, const float* label, float* gz,

@@ -1,3 +1,4 @@
+# round-2 evidence: everything DESIGN.md section 5 cites, written under gpurun_out/ (copied to profiles/ by hand)
 set -e
 R=$GRAFT_REPO_ROOT
 cd $R
@@ -5,7 +6,11 @@ timeout -k 10 400 python bench.py > gpurun_out/r02_bench.json 2> gpurun_out/r02_
 timeout -k 10 400 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r02_bench_k20.json 2> gpurun_out/r02_bench_k20.err
 timeout -k 10 900 python scripts/bench_configs.py --graphed > gpurun_out/r02_other_configs.jsonl 2> gpurun_out/r02_other_configs.err
 timeout -k 10 300 python scripts/exp/gemm_shapes.py crossnet > gpurun_out/r02_crossnet_gemm.txt 2>&1
+timeout -k 10 100 python scripts/exp/gemm_din.py >> gpurun_out/r02_crossnet_gemm.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r02_prof_bench -o b -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/r02_prof_bench.log 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r02_prof_C26 -o c -- python3 $R/scripts/bench_configs.py --graphed C26 > $R/gpurun_out/r02_prof_C26.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r02_prof_E -o e -- python3 $R/scripts/bench_configs.py --graphed E > $R/gpurun_out/r02_prof_E.log 2>&1
+cd $R
+bash scripts/exp/pmc_din.sh > gpurun_out/r02_pmc_din.log 2>&1
 echo done

@@ -278,6 +278,32 @@ def test_fused_step_equals_generic_step_and_is_deterministic():
         assert torch.equal(v[1] if isinstance(v, tuple) else v, snap[k]), k       # run-to-run bit identical
 
 
+def test_fused_step_notices_a_replaced_column():
+    """The per-batch checks are cached per batch dict: replacing a tensor inside a dict that was seen before must be
+    noticed -- a wrong dtype is refused, a new id column is used."""
+    from explicit_tf2_recommendation_amd import engine, data
+    B, F, V = 512, 5, 5547
+    layer, names, gen = make16(B, F, V, 29, "zipf")
+    step = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, use_graph=True)
+    h0, h1 = gen.batch(B), gen.batch(B)
+    d0 = data.to_device(h0)
+    step(d0)
+    step(d0)                                                 # second call: the cached path
+    d0[names[2]] = d0[names[2]].to(torch.int32)
+    with pytest.raises(ValueError):
+        step(d0)
+    h0[names[2]] = h1[names[2]]                              # another column of valid ids of the same field
+    d0[names[2]] = data.to_device(h1)[names[2]]
+    loss = step(d0)
+    ref_loss, ref = oracle_grads(layer, names, h0)
+    assert abs(loss.item() - ref_loss) <= 1e-5 * max(1, abs(ref_loss))
+    ids, rows, nu = step.gradients()["embed.embeddings"]
+    nu = int(nu.item())
+    touched = np.unique(L.index_assemble(h0, names))
+    assert np.array_equal(ids.cpu().numpy()[:nu], touched)
+    assert close(rows.cpu().numpy()[:nu], ref["embed.embeddings"][touched])
+
+
 def test_fused_step_flags_contract_violation():
     from explicit_tf2_recommendation_amd import engine, data
     B, F, V = 256, 5, 5547

@@ -255,6 +255,22 @@ def test_gemm_tall_skinny(ops, M, N, K):
     assert np.abs(aux.cpu().numpy() - (ref + bias)).max() <= tol
 
 
+@pytest.mark.parametrize("M,N,strided", [(4096, 36, False), (4096, 1, False), (8192, 256, True), (8193, 40, False),
+                                          (16384, 33, True), (300, 3492, False), (1, 7, False), (5000, 200, True)])
+def test_colsum_one_pass_and_two_stage(ops, M, N, strided):
+    """Column sums: the one-launch kernel (M <= 8192, M*N <= 2^21: bias gradients) and the two-stage one on both sides of
+    the switch, contiguous and as a column slice of a wider matrix; fixed summation order -> run-to-run bit-identical."""
+    r = H.rng(M + N)
+    X = r.normal(size=(M, N + (5 if strided else 0))).astype(np.float32)
+    Xd = dev(X)
+    view = Xd[:, 2:2 + N] if strided else Xd
+    ref = (X[:, 2:2 + N] if strided else X).astype(np.float64).sum(0)
+    a = ops.colsum(view)
+    b = ops.colsum(view)
+    assert torch.equal(a, b)
+    assert np.abs(a.cpu().numpy() - ref).max() <= 2e-6 * np.sqrt(M) * max(1.0, np.abs(ref).max())
+
+
 def test_dense_helpers(ops):
     r = H.rng(12)
     post = r.normal(size=(100, 33)).astype(np.float32)
@@ -589,6 +605,13 @@ def test_colsort_shard_map_fixed_and_owner_side(ops, P, B, F, zipf):
         assert np.array_equal(o[q, :counts[q]], table.cpu().numpy()[theirs[q, 2:2 + counts[q]]])
         assert np.all(o[q, counts[q]:] == 123.0)         # unused slots are not touched
     assert oob.item() == 0
+    out20 = torch.full((P * cap, 20), 123.0, device="cuda")          # only the leading 80 bytes of every row
+    check(lib.rec_emb_gather_lists_f32(vp(table), rps, 20, 32, vp(mt), P, cap, vp(out20), vp(oob), st),
+          "rec_emb_gather_lists_f32")
+    o20 = out20.cpu().numpy().reshape(P, cap, 20)
+    for q in range(P):
+        assert np.array_equal(o20[q, :counts[q]], table.cpu().numpy()[theirs[q, 2:2 + counts[q]], :20])
+        assert np.all(o20[q, counts[q]:] == 123.0)
     n = P * cap
     uniq, seg, perm = torch.empty(n, **i64), torch.empty(n + 1, **i32), torch.empty(n, **i32)
     nu_d = torch.zeros(1, **i64)

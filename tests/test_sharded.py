@@ -115,7 +115,7 @@ class OracleStepBackend:
     def __init__(self, step, field_dims, field_offsets):
         self.step = step
         m = step.P * step.cap
-        self.rows_local = torch.zeros((m, 32))
+        self.rows_local = torch.zeros((m, 20))
         self.rows_theirs = torch.zeros((m, 20))
 
     def begin(self):
@@ -154,10 +154,10 @@ class OracleStepBackend:
     def gather(self, table, pl):
         st = self.step
         msg = pl["msg_theirs"]
-        out = torch.zeros((st.P * st.cap, 32))
+        out = torch.zeros((st.P * st.cap, 20))
         for q in range(st.P):
             c = int(msg[q, 0])
-            out[q * st.cap:q * st.cap + c] = table[msg[q, 2:2 + c]]
+            out[q * st.cap:q * st.cap + c] = table[msg[q, 2:2 + c], :20]
         return out
 
     def rows_step(self, pl, rows_local, y):
