@@ -195,11 +195,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(i):
+    def run(i, n):
         if args.generic:
             step(batches[i % n_batches])
-        else:   # the next batch is announced: its de-duplication plan is built while this one is differentiated
-            step(batches[i % n_batches], next_inputs=batches[(i + 1) % n_batches])
+        else:   # the next batch is announced: its de-duplication plan is built while this one is differentiated (the
+                # last step of a run announces the first batch of the next run: every run starts at batch 0)
+            step(batches[i % n_batches], next_inputs=batches[(i + 1) % n_batches if i + 1 < n else 0])
 
     # launch-bound inner loop: the resident batches are cycled through --cycle steps per captured hipGraph (one graph
     # launch costs ~20 us of idle GPU); --step-graphs keeps one graph per step
@@ -230,7 +231,7 @@ def main():
                 step.many(batches[b0:b0 + Cy])
                 i += Cy
         while i < n:
-            run(i)
+            run(i, n)
             i += 1
 
     nw = max(args.warmup, 2 * n_batches)                 # warm-up also captures the hipGraphs of the resident batches
@@ -318,7 +319,7 @@ def main():
         launch(10)
         torch.cuda.synchronize()
         gg = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gg):
+        with torch.cuda.graph(gg, capture_error_mode=engine.CAPTURE_MODE):
             launch(reps)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         gg.replay()

@@ -16,6 +16,13 @@ from . import ops
 from ._lib import lib, check
 
 
+# Stream captures use the thread-local error mode: with a process group alive, ProcessGroupNCCL's watchdog thread polls
+# the events of finished collectives (hipEventQuery) whenever it likes, and in the default global mode such a call from
+# ANOTHER thread during a capture invalidates the capture and terminates the process ("operation not permitted when
+# stream is capturing") -- seen in bench.py --sharded, where graphs are captured after collectives have run.
+CAPTURE_MODE = "thread_local"
+
+
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -238,7 +245,7 @@ class DeepFMTrainStep:
             self._enqueue(cols, y, stream, self.t)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                 cs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
                 self._enqueue(cols, y, cs, self.t)
             self._graphs[key] = (g, cols, y)      # keep the inputs alive: the graph holds their addresses
@@ -562,7 +569,7 @@ class DeepFMFusedStep:
                 enqueue_all()                                    # warm-up (sets the kernel attributes)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                     enqueue_all()
                 ent = (g, seq, then_cols)                        # keep the inputs alive: the graph holds addresses
                 self._graphs[gkey] = ent
@@ -919,7 +926,7 @@ class ShardedDeepFMStep:
             run()                                            # communicators and lazy initialisation: not captured
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                 run()
             graphs[key] = g
         g.replay()
@@ -974,7 +981,7 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         for p in self.params:
             p.grad = None
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
             self.loss = self._fwd_bwd()
         self.grads = [p.grad for p in self.params]           # tensors of the graph's pool: refreshed by every replay
 
