@@ -51,28 +51,46 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int64_t M, int64_t N, int
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
+  // the next K-tile travels (global -> registers) while the current one is multiplied: with one 64x64 tile per CU -- a
+  // mid-size product such as [4096,352] x [352,200] fills the chip exactly once -- nothing else hides the ~2 us of a
+  // load -> LDS -> barrier -> MFMA round (22 rounds: 51 us for 0.58 GFLOP)
+  constexpr int PERA = (BM * BK) / 256, PERB = (BN * BK) / 256;
+  float ra[PERA], rb[PERB];
+  auto fetch = [&](int64_t k0) {
 #pragma unroll
-    for (int i = 0; i < (BM * BK) / 256; ++i) {
+    for (int i = 0; i < PERA; ++i) {
       int e = tid + i * 256;
       int m, k;
       if (TA == 0) { m = e / BK; k = e % BK; } else { k = e / BM; m = e % BM; }
       int64_t gm = m0 + m, gk = k0 + k;
-      float v = 0.f;
-      if (gm < M && gk < k_end) v = (TA == 0) ? A[gm * lda + gk] : A[gk * lda + gm];
-      As[k][m] = v;
+      ra[i] = (gm < M && gk < k_end) ? ((TA == 0) ? A[gm * lda + gk] : A[gk * lda + gm]) : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < (BN * BK) / 256; ++i) {
+    for (int i = 0; i < PERB; ++i) {
       int e = tid + i * 256;
       int n, k;
       if (TB == 0) { k = e / BN; n = e % BN; } else { n = e / BK; k = e % BK; }
       int64_t gn = n0 + n, gk = k0 + k;
-      float v = 0.f;
-      if (gn < N && gk < k_end) v = (TB == 0) ? B[gk * ldb + gn] : B[gn * ldb + gk];
-      Bs[k][n] = v;
+      rb[i] = (gn < N && gk < k_end) ? ((TB == 0) ? B[gk * ldb + gn] : B[gn * ldb + gk]) : 0.f;
     }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < PERA; ++i) {
+      int e = tid + i * 256;
+      if (TA == 0) As[e % BK][e / BK] = ra[i]; else As[e / BM][e % BM] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < PERB; ++i) {
+      int e = tid + i * 256;
+      if (TB == 0) Bs[e / BN][e % BN] = rb[i]; else Bs[e % BK][e / BK] = rb[i];
+    }
+  };
+  if (k_begin < k_end) fetch(k_begin);
+  for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
+    stage();
     __syncthreads();
+    if (k0 + BK < k_end) fetch(k0 + BK);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
