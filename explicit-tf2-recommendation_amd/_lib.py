@@ -29,6 +29,7 @@ SIGNATURES = {
     "rec_crossnet_mat_bwd_elem_f32": (i32, [p, p, p, p, p, i32, i64, p]),
     "rec_act_bwd_f32": (i32, [i32, p, p, p, i64, p]),
     "rec_colsum_workspace_bytes": (sz, [i64, i64]),
+    "rec_colsum_fused_f32": (i32, [p, i64, i64, i64, p, p, p, p]),
     "rec_colsum_f32": (i32, [p, i64, i64, i64, p, p, p]),
     "rec_axpby_f32": (i32, [f32, p, f32, p, i64, p]),
     "rec_copy_cols_f32": (i32, [p, i64, p, i64, i64, i64, p]),

@@ -128,6 +128,56 @@ __global__ __launch_bounds__(1024) void colsum_onepass_kernel(const float* __res
   }
 }
 
+// Both stages in ONE launch: every workgroup leaves its partial, and the one that arrives last at the column block's
+// counter (integer atomics: exact) adds the partials of all row blocks -- in the same fixed order as colsum_final_kernel,
+// so the result does not depend on which workgroup that is -- and puts the counter back to zero.  The bias gradients of
+// the MLP / attention layers are 10-15 such sums per train step, each of them two launches at the launch floor before.
+__global__ __launch_bounds__(256) void colsum_fused_kernel(const float* __restrict__ X, int64_t M, int64_t N, int64_t ldx,
+                                                           int64_t rows_per_block, float* __restrict__ part, int nrb,
+                                                           int* __restrict__ counters, float* __restrict__ out) {
+  __shared__ float sh[8][33];
+  __shared__ int last_s;
+  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const int64_t col = (int64_t)blockIdx.x * 32 + c;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  float acc = 0.f;
+  if (col < N)
+    for (int64_t i = r0 + r; i < r1; i += 8) acc += X[i * ldx + col];
+  sh[r][c] = acc;
+  __syncthreads();
+  // Partials and the counter are accessed with device-scope (write-through / cache-bypassing) operations, so no L2
+  // write-back is needed to hand them from one workgroup to another: a release fence per workgroup costs an L2 flush
+  // each, and thousands of them made the wide sums (DIN's [4096, 3492], CrossNet's [16384, 835]) slower than two launches.
+  if (r == 0 && col < N) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += sh[q][c];
+    __hip_atomic_store(&part[(int64_t)blockIdx.y * N + col], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __builtin_amdgcn_s_waitcnt(0);                     // this wave's partials have reached the coherent level
+  __syncthreads();
+  if (threadIdx.x == 0)
+    last_s = __hip_atomic_fetch_add(&counters[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nrb - 1;
+  __syncthreads();
+  if (!last_s) return;                               // workgroup-uniform
+  acc = 0.f;
+  if (col < N) {
+#pragma unroll 4
+    for (int q = r; q < nrb; q += 8)
+      acc += __hip_atomic_load(&part[(int64_t)q * N + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  sh[r][c] = acc;
+  __syncthreads();
+  if (r == 0 && col < N) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += sh[q][c];
+    out[col] = s;
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(&counters[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ __launch_bounds__(256) void axpby_kernel(float a, const float* __restrict__ x, float b,
                                                     float* __restrict__ y, int64_t n) {
   int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -581,6 +631,18 @@ extern "C" int rec_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx,
                        out);
     REC_LAUNCH_CHECK();
   }
+  return REC_OK;
+}
+
+extern "C" int rec_colsum_fused_f32(const float* X, int64_t M, int64_t N, int64_t ldx, float* out, float* workspace,
+                                    int* counters, void* stream) {
+  if (!X || !out || !counters || M < 0 || N <= 0 || ldx < N) return REC_E_ARG;
+  int nrb = colsum_row_blocks(M);
+  if (!workspace) return REC_E_WORKSPACE;
+  int64_t rpb = ceil_div64(M > 0 ? M : 1, nrb);
+  hipLaunchKernelGGL(colsum_fused_kernel, dim3((unsigned)ceil_div64(N, 32), (unsigned)nrb), dim3(256), 0,
+                     as_stream(stream), X, M, N, ldx, rpb, workspace, nrb, counters, out);
+  REC_LAUNCH_CHECK();
   return REC_OK;
 }
 

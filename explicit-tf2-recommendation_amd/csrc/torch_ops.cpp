@@ -8,6 +8,7 @@
 // reference (2.FM/ModelManager.py:87-96) stays in layers.py; autograd stays in functional.py (its Functions call these
 // operators in their forward / backward).  Dispatch key CUDA = the ROCm device of PyTorch-ROCm.
 #include <ATen/ATen.h>
+#include <c10/hip/HIPGraphsC10Utils.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -118,10 +119,30 @@ Tensor act_bwd(int64_t act, const Tensor& post, const Tensor& dpost) {
   return out;
 }
 
+// Arrival counters of rec_colsum_fused_f32: one zero-initialised int32 buffer per device, handed out as a ring (a call
+// takes the next ceil(N/32) slots, so calls that overlap on different streams do not meet; every call leaves its slots
+// zero).  Allocated by the first call outside a stream capture (its memory must not belong to a graph's pool); until
+// then, and for very wide matrices, the two-launch form is used.
+constexpr int64_t COLSUM_RING = 1 << 16;
+static Tensor* g_colsum_ring[64] = {nullptr};
+static int64_t g_colsum_pos[64] = {0};
+
 Tensor colsum(const Tensor& X, const optional<Tensor>& out_) {
   const int64_t M = X.size(0), N = X.size(1);
   Tensor out = out_.has_value() ? *out_ : at::empty({N}, X.options());
   Tensor ws = at::empty({(int64_t)(rec_colsum_workspace_bytes(M, N) / 4)}, X.options());
+  const int dev = X.device().index();
+  const int64_t nblk = (N + 31) / 32;
+  if (dev >= 0 && dev < 64 && !g_colsum_ring[dev] &&
+      c10::hip::currentStreamCaptureStatusMayInitCtx() == c10::hip::CaptureStatus::None)
+    g_colsum_ring[dev] = new Tensor(at::zeros({COLSUM_RING}, X.options().dtype(at::kInt)));   // never freed: outlives
+  if (dev >= 0 && dev < 64 && g_colsum_ring[dev] && nblk <= COLSUM_RING / 4 && M > 1024) {     // the HIP context
+    if (g_colsum_pos[dev] + nblk > COLSUM_RING) g_colsum_pos[dev] = 0;
+    int* cnt = g_colsum_ring[dev]->data_ptr<int>() + g_colsum_pos[dev];
+    g_colsum_pos[dev] += nblk;
+    check(rec_colsum_fused_f32(fp(X), M, N, X.stride(0), fpm(out), fpm(ws), cnt, stream_of(X)), "rec_colsum_fused_f32");
+    return out;
+  }
   check(rec_colsum_f32(fp(X), M, N, X.stride(0), fpm(out), fpm(ws), stream_of(X)), "rec_colsum_f32");
   return out;
 }

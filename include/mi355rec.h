@@ -132,6 +132,11 @@ int rec_act_bwd_f32(int act, const float* post, const float* dpost, float* dpre,
  * rec_colsum_workspace_bytes(M,N) bytes. */
 size_t rec_colsum_workspace_bytes(int64_t M, int64_t N);
 int rec_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx, float* out, float* workspace, void* stream);
+/* The same in ONE launch: `counters` = ceil(N/32) ints that are ZERO on entry and zero again on exit (the workgroup that
+ * arrives last at a column block's counter adds the partials of all row blocks, in the fixed order of the two-stage
+ * form: bit-identical results).  Calls that share counters must not run concurrently. */
+int rec_colsum_fused_f32(const float* X, int64_t M, int64_t N, int64_t ldx, float* out, float* workspace, int* counters,
+                         void* stream);
 /* y = a*x + b*y over n elements */
 int rec_axpby_f32(float a, const float* x, float b, float* y, int64_t n, void* stream);
 /* dst[r, c0:c0+w] = src[r, 0:w]   (concat / split along the feature axis) */

@@ -269,6 +269,23 @@ def test_colsum_one_pass_and_two_stage(ops, M, N, strided):
     b = ops.colsum(view)
     assert torch.equal(a, b)
     assert np.abs(a.cpu().numpy() - ref).max() <= 2e-6 * np.sqrt(M) * max(1.0, np.abs(ref).max())
+    # the one-launch form (arrival counters; what torch.ops.mi355rec.colsum uses above 1024 rows) against the two-stage
+    # form through the C ABI: the same summation order, bit for bit; the counters are zero again afterwards
+    import ctypes as C
+    from explicit_tf2_recommendation_amd._lib import lib, check
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ws = torch.empty(lib.rec_colsum_workspace_bytes(M, N) // 4 + 1, device="cuda")
+    two, one = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    cnt = torch.zeros((N + 31) // 32, dtype=torch.int32, device="cuda")
+    check(lib.rec_colsum_f32(vp(view), M, N, view.stride(0), vp(two), vp(ws), st), "rec_colsum_f32")
+    for _ in range(3):
+        check(lib.rec_colsum_fused_f32(vp(view), M, N, view.stride(0), vp(one), vp(ws), vp(cnt), st), "rec_colsum_fused_f32")
+        if M > 1024:
+            assert torch.equal(one, two)
+        else:
+            assert np.abs(one.cpu().numpy() - ref).max() <= 2e-6 * np.sqrt(M) * max(1.0, np.abs(ref).max())
+        assert int(cnt.abs().sum().item()) == 0
 
 
 def test_dense_helpers(ops):
