@@ -12,5 +12,13 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpu
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r02_prof_C26 -o c -- python3 $R/scripts/bench_configs.py --graphed C26 > $R/gpurun_out/r02_prof_C26.log 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r02_prof_E -o e -- python3 $R/scripts/bench_configs.py --graphed E > $R/gpurun_out/r02_prof_E.log 2>&1
 cd $R
-bash scripts/exp/pmc_din.sh > gpurun_out/r02_pmc_din.log 2>&1
-echo done
+true
+echo done1
+# PMC traffic (two separate counter passes of the same bench command), aggregated by scripts/pmc_traffic.py
+cd /tmp && export TMPDIR=/tmp
+rm -rf $R/gpurun_out/pmc_f $R/gpurun_out/pmc_w
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_f -o f -- python3 $R/bench.py --steps 20 --warmup 8 --no-cpu-baseline --adam-steps 0 > $R/gpurun_out/pmc_f.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_w -o w -- python3 $R/bench.py --steps 20 --warmup 8 --no-cpu-baseline --adam-steps 0 > $R/gpurun_out/pmc_w.log 2>&1
+cd $R
+python scripts/pmc_traffic.py gpurun_out/pmc_f/f_counter_collection.csv gpurun_out/pmc_w/w_counter_collection.csv > gpurun_out/pmc_traffic.log 2>&1 || true
+echo done2
