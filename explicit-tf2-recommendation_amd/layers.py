@@ -398,10 +398,13 @@ class ConcatCols(torch.autograd.Function):
         g = g.contiguous()
         outs = []
         c = 0
-        for w in ctx.widths:
-            blk = torch.empty((g.shape[0], w), dtype=torch.float32, device=g.device)
-            ops.copy_cols(g[:, c:c + w], blk)
-            outs.append(blk)
+        for i, w in enumerate(ctx.widths):
+            if ctx.needs_input_grad[i]:                  # input features (the continuous columns) need no gradient
+                blk = torch.empty((g.shape[0], w), dtype=torch.float32, device=g.device)
+                ops.copy_cols(g[:, c:c + w], blk)
+                outs.append(blk)
+            else:
+                outs.append(None)
             c += w
         return tuple(outs)
 
@@ -416,6 +419,8 @@ def _cont_block(inputs, names, device):
         if t.dim() == 1:
             t = t.unsqueeze(1)
         cols.append(t.contiguous())
+    if len(cols) > 1:                                     # one [B, n_cont] block: one copy into the concatenation
+        return [torch.cat(cols, dim=1)]
     return cols
 
 
