@@ -786,6 +786,9 @@ struct ColSegArgs {
   // fixed-capacity exchange layout (sharded step): slot of every unique id (index = its rank in the batch's ascending
   // list) inside the [owners x capacity] send buffer; null = the compact list itself
   const int32_t* slot_map;
+  // bias-corrected step size of the lazy Adam read from device memory (set by rec_adam_advance_f32): the train step then
+  // holds no per-step host scalar and can be replayed from a hipGraph; null = lr_t above
+  const float* lr_t_dev;
 };
 
 // m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2 ; var <- var - lr_t m / (sqrt(v) + eps)   (rec_adam_rows_f32's formula)
@@ -933,7 +936,9 @@ __global__ __launch_bounds__(256) void colseg_sum_kernel(ColSegArgs k) { colseg_
 // A wave takes 4 consecutive runs from each sixteenth of a column (when B is a multiple of 64), so that neighbouring
 // hot ids -- the synthetic Zipf draws make the smallest ids of a field the frequent ones -- fall to different waves.
 constexpr int FIX_T = 1024;
-__device__ __forceinline__ void fixup_body(const ColSegArgs& k, int bidx) {
+__device__ __forceinline__ void fixup_body(const ColSegArgs& k_in, int bidx) {
+  ColSegArgs k = k_in;
+  if (k.lr_t_dev) k.lr_t = *k.lr_t_dev;
   const float4* __restrict__ vals = k.vals;
   const float* __restrict__ gz = k.gz;
   const int64_t B = k.B;
@@ -1214,7 +1219,7 @@ static int launch_post(bool direct, int F, int64_t B, const float* gz, const flo
     k.slot_map = adam->slot_map;
   } else if (adam) {
     k.table = adam->table; k.m_e = adam->m_e; k.v_e = adam->v_e; k.m_w = adam->m_w; k.v_w = adam->v_w; k.V = adam->V;
-    k.lr_t = adam->lr_t; k.b1 = adam->b1; k.b2 = adam->b2; k.eps = adam->eps;
+    k.lr_t = adam->lr_t; k.b1 = adam->b1; k.b2 = adam->b2; k.eps = adam->eps; k.lr_t_dev = adam->lr_t_dev;
   }
   if (direct) {
     unsigned nbf = (unsigned)F * (unsigned)ceil_div64(B, FIX_T);
@@ -1299,6 +1304,28 @@ extern "C" int rec_deepfm_fused_post_direct_adam_f32(int F, int64_t B, const flo
   ColSegArgs a{};
   a.table = table; a.m_e = m_e; a.v_e = v_e; a.m_w = m_w; a.v_w = v_w; a.V = V;
   a.lr_t = lr * sqrtf(1.f - b2p) / (1.f - b1p); a.b1 = b1; a.b2 = b2; a.eps = eps;
+  return launch_post(true, F, B, gz, vals, dK0, db0, dK1, db1, dK2, db2, dbias, loss, workspace, perm, col_uid, col_seg,
+                     col_nu, uniq_ids, g_embed_rows, g_w_rows, n_uniq, 0, stream, &a);
+}
+
+// ... with the step size read from device memory (lr_t_dev, advanced by rec_adam_advance_f32 on the same stream): no
+// per-step host scalar, so a whole train step -- this launch included -- replays from a hipGraph
+extern "C" int rec_deepfm_fused_post_direct_adam_dev_f32(int F, int64_t B, const float* gz, const float* vals, float* dK0,
+                                                         float* db0, float* dK1, float* db1, float* dK2, float* db2,
+                                                         float* dbias, float* loss, void* workspace, const int32_t* perm,
+                                                         const int64_t* col_uid, const int32_t* col_seg,
+                                                         const int32_t* col_nu, int64_t* uniq_ids, float* g_embed_rows,
+                                                         float* g_w_rows, int64_t* n_uniq, float* table, int64_t ld,
+                                                         int64_t V, float* m_e, float* v_e, float* m_w, float* v_w,
+                                                         const float* lr_t_dev, float b1, float b2, float eps,
+                                                         void* stream) {
+  if (!table || !m_e || !v_e || !m_w || !v_w || !lr_t_dev || V <= 0) return REC_E_ARG;
+  if (ld != LD || (reinterpret_cast<uintptr_t>(table) & 15) != 0 || (reinterpret_cast<uintptr_t>(m_e) & 15) != 0 ||
+      (reinterpret_cast<uintptr_t>(v_e) & 15) != 0)
+    return REC_E_UNSUPPORTED;
+  ColSegArgs a{};
+  a.table = table; a.m_e = m_e; a.v_e = v_e; a.m_w = m_w; a.v_w = v_w; a.V = V;
+  a.lr_t = 0.f; a.lr_t_dev = lr_t_dev; a.b1 = b1; a.b2 = b2; a.eps = eps;
   return launch_post(true, F, B, gz, vals, dK0, db0, dK1, db1, dK2, db2, dbias, loss, workspace, perm, col_uid, col_seg,
                      col_nu, uniq_ids, g_embed_rows, g_w_rows, n_uniq, 0, stream, &a);
 }

@@ -562,6 +562,41 @@ __global__ __launch_bounds__(256) void adam_rows_lazy_kernel(float* __restrict__
   var[id * ld + d] = var[id * ld + d] - lr_t * mm / (sqrtf(vv) + eps);
 }
 
+// ---- device-side step size: *step += 1, *lr_t = table[min(step, n) - 1].  The table holds Keras' bias-corrected step size
+// of steps 1..n as the host computes it (adam_lr_t: float32 pow), so a graph-replayed train step uses bit for bit the
+// values an eagerly enqueued one gets passed; beyond the table the correction factors are 1 in float32 (b2^t < 2^-24).
+__global__ void adam_advance_kernel(int64_t* __restrict__ step, const float* __restrict__ tab, int64_t n,
+                                    float* __restrict__ lr_t) {
+  const int64_t t = *step + 1;
+  *step = t;
+  *lr_t = tab[(t < n ? t : n) - 1];
+}
+
+// Adam on several small dense parameters in ONE launch (the 7 dense parameters of DeepFM were 7 launches at the launch
+// floor); arithmetic of adam_dense_kernel, step size from device memory
+constexpr int ADAM_MULTI_MAX = 16;
+struct AdamMulti {
+  float* var[ADAM_MULTI_MAX]; float* m[ADAM_MULTI_MAX]; float* v[ADAM_MULTI_MAX]; const float* g[ADAM_MULTI_MAX];
+  int64_t end[ADAM_MULTI_MAX];      // running element count: tensor i covers [end[i-1], end[i])
+  int n;
+};
+__global__ __launch_bounds__(256) void adam_dense_multi_kernel(AdamMulti a, const float* __restrict__ lr_t_dev, float b1,
+                                                               float b2, float eps) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.end[a.n - 1]) return;
+  int i = 0;
+  while (t >= a.end[i]) ++i;
+  const int64_t e = t - (i ? a.end[i - 1] : 0);
+  const float lr_t = *lr_t_dev;
+  float gg = a.g[i][e];
+  float mm = a.m[i][e], vv = a.v[i][e];
+  mm = mm + (gg - mm) * (1.f - b1);
+  vv = vv + (gg * gg - vv) * (1.f - b2);
+  a.m[i][e] = mm;
+  a.v[i][e] = vv;
+  a.var[i][e] = a.var[i][e] - lr_t * mm / (sqrtf(vv) + eps);
+}
+
 inline float adam_lr_t(float lr, float b1, float b2, int64_t t) {
   // float32 arithmetic as Keras does (tf.pow on float32 scalars)
   float b1p = powf(b1, (float)t), b2p = powf(b2, (float)t);
@@ -763,6 +798,37 @@ extern "C" int rec_adam_dense_f32(float* var, float* m, float* v, const float* g
   if (n == 0) return REC_OK;
   hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, as_stream(stream), var, m, v,
                      g, n, adam_lr_t(lr, b1, b2, t), b1, b2, eps);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" float rec_adam_lr_t_f32(float lr, float b1, float b2, int64_t t) { return adam_lr_t(lr, b1, b2, t); }
+
+extern "C" int rec_adam_advance_f32(int64_t* step_dev, const float* lr_table, int64_t n_table, float* lr_t_dev,
+                                    void* stream) {
+  if (!step_dev || !lr_table || !lr_t_dev || n_table <= 0) return REC_E_ARG;
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, as_stream(stream), step_dev, lr_table, n_table, lr_t_dev);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_adam_dense_multi_f32(int n_tensors, float* const* var, float* const* m, float* const* v,
+                                        const float* const* g, const int64_t* numel, const float* lr_t_dev, float b1,
+                                        float b2, float eps, void* stream) {
+  if (n_tensors <= 0 || !var || !m || !v || !g || !numel || !lr_t_dev) return REC_E_ARG;
+  if (n_tensors > ADAM_MULTI_MAX) return REC_E_UNSUPPORTED;
+  AdamMulti a{};
+  int64_t tot = 0;
+  for (int i = 0; i < n_tensors; ++i) {
+    if (!var[i] || !m[i] || !v[i] || !g[i] || numel[i] < 0) return REC_E_ARG;
+    a.var[i] = var[i]; a.m[i] = m[i]; a.v[i] = v[i]; a.g[i] = g[i];
+    tot += numel[i];
+    a.end[i] = tot;
+  }
+  a.n = n_tensors;
+  if (tot == 0) return REC_OK;
+  hipLaunchKernelGGL(adam_dense_multi_kernel, dim3((unsigned)ceil_div64(tot, 256)), dim3(256), 0, as_stream(stream), a,
+                     lr_t_dev, b1, b2, eps);
   REC_LAUNCH_CHECK();
   return REC_OK;
 }

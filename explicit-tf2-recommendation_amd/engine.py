@@ -348,6 +348,23 @@ class DeepFMFusedStep:
                           for name, p in layer.named_parameters()}
             self.side_e = torch.empty((n, 3, 16), **f32)
             self.side_w = torch.empty((n, 3, 1), **f32)
+        if self._fused_lazy():
+            # the step counter and the bias-corrected step size live on the device (rec_adam_advance_f32): the train step
+            # holds no per-step host scalar, so it is captured and replayed like the gradient-only step.  The table holds
+            # lr_t of steps 1..N exactly as the host-side entry points compute it; beyond it the corrections are 1.0f
+            N = 32768
+            tab = [lib.rec_adam_lr_t_f32(lr, 0.9, 0.999, t) for t in range(1, N + 1)]
+            self._lr_tab = torch.tensor(tab, **f32)
+            self._step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+            self._lr_t_dev = torch.zeros(1, **f32)
+            params = dict(layer.named_parameters())
+            names = list(self.g)
+            k = len(names)
+            self._multi = (k, (C.c_void_p * k)(*[params[nm].data_ptr() for nm in names]),
+                           (C.c_void_p * k)(*[self.state[nm][0].data_ptr() for nm in names]),
+                           (C.c_void_p * k)(*[self.state[nm][1].data_ptr() for nm in names]),
+                           (C.c_void_p * k)(*[self.g[nm].data_ptr() for nm in names]),
+                           (C.c_int64 * k)(*[self.g[nm].numel() for nm in names]))
         self._graphs = {}
 
     def _sort(self, cols, buf, stream):
@@ -397,13 +414,15 @@ class DeepFMFusedStep:
             params = dict(self.layer.named_parameters())
             pe = params["embed.embeddings"]
             (me, ve), (mw, vw) = self.state["embed.embeddings"], self.state["w.embeddings"]
-            check(lib.rec_deepfm_fused_post_direct_adam_f32(
+            check(lib.rec_adam_advance_f32(_p(self._step_dev), _p(self._lr_tab), self._lr_tab.numel(),
+                                           _p(self._lr_t_dev), st), "rec_adam_advance_f32")
+            check(lib.rec_deepfm_fused_post_direct_adam_dev_f32(
                 self.F, self.B, _p(self.gz), _p(self.vals), _p(g["MLP_layer1.kernel_0"]), _p(g["MLP_layer1.bias_0"]),
                 _p(g["MLP_layer1.kernel_1"]), _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]),
                 _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(self.loss), _p(self.ws), _p(pl["perm"]),
                 _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.uniq_ids), _p(self.g_embed_rows),
-                _p(self.g_w_rows), _p(self.n_uniq), _p(pe), pe.stride(0), self.V, _p(me), _p(ve), _p(mw), _p(vw), t,
-                self.lr, 0.9, 0.999, 1e-7, st), "rec_deepfm_fused_post_direct_adam_f32")
+                _p(self.g_w_rows), _p(self.n_uniq), _p(pe), pe.stride(0), self.V, _p(me), _p(ve), _p(mw), _p(vw),
+                _p(self._lr_t_dev), 0.9, 0.999, 1e-7, st), "rec_deepfm_fused_post_direct_adam_dev_f32")
             return
         if not self.direct:
             check(lib.rec_deepfm_fused_post_f32(
@@ -422,6 +441,13 @@ class DeepFMFusedStep:
 
     def _optimizer(self, t, st):
         lr, b1, b2, eps = self.lr, 0.9, 0.999, 1e-7
+        if self._fused_lazy():
+            # the tables were updated inside the post launch; the dense parameters follow in ONE launch, with the
+            # step size the post launch used (device memory)
+            k, var, m, v, g, numel = self._multi
+            check(lib.rec_adam_dense_multi_f32(k, var, m, v, g, numel, _p(self._lr_t_dev), b1, b2, eps, st),
+                  "rec_adam_dense_multi_f32")
+            return
         params = dict(self.layer.named_parameters())
         for name, grad in self.g.items():
             m, v = self.state[name]
@@ -534,7 +560,7 @@ class DeepFMFusedStep:
                 inline.append(i)
         other = (1 - cur_half) * half
         then_bufs = [other + j for j in range(len(then_cols))]
-        graphed = self.use_graph and self.optimizer is None
+        graphed = self.use_graph and (self.optimizer is None or self._fused_lazy())
         gkey = (tuple(keys), tuple(y.data_ptr() for _, y in seq), tuple(then_keys), tuple(bufs), tuple(inline))
 
         def enqueue_all():
@@ -553,29 +579,31 @@ class DeepFMFusedStep:
             for i in range(n):
                 if i > 0:
                     self._launch_main(seq[i][0], seq[i][1], st, bufs[i])
+                t = t_base + i + 1                               # 1-based step (host scalar of the non-graphed optimizers)
+                self._launch_post(bufs[i], st, t)
                 if self.optimizer is not None:
-                    self.t += 1
-                self._launch_post(bufs[i], st, self.t)
-                if self.optimizer is not None:
-                    self._optimizer(self.t, st)
+                    self._optimizer(t, st)
             if then_cols:
                 main.wait_stream(side)                           # join: the next call relies on the other half
 
+        t_base = self.t
         if not graphed:
             enqueue_all()
         else:
             ent = self._graphs.get(gkey)
             if ent is None:
-                enqueue_all()                                    # warm-up (sets the kernel attributes)
+                # first call with these batches: enqueued eagerly -- that IS this call's work (and sets the kernel
+                # attributes) -- and then captured, without running, for the calls to come.  (With an optimizer in the
+                # step a warm-up followed by a replay would apply the update twice.)
+                enqueue_all()
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                     enqueue_all()
-                ent = (g, seq, then_cols)                        # keep the inputs alive: the graph holds addresses
-                self._graphs[gkey] = ent
-            ent[0].replay()
-        if self.optimizer is None:
-            self.t += n
+                self._graphs[gkey] = (g, seq, then_cols)         # keep the inputs alive: the graph holds addresses
+            else:
+                ent[0].replay()
+        self.t = t_base + n
         self._prefetched = dict(zip(then_keys, then_bufs))
         self._half = 1 - cur_half if then_cols else cur_half
         return self.loss

@@ -169,6 +169,16 @@ int rec_bce_fwd_bwd_f32(const float* y, const float* p, int64_t n, float* loss, 
  * dense: m += (g-m)(1-b1); v += (g*g-v)(1-b2); var -= lr_t*m/(sqrt(v)+eps). */
 int rec_adam_dense_f32(float* var, float* m, float* v, const float* g, int64_t n, int64_t t, float lr,
                        float b1, float b2, float eps, void* stream);
+/* Keras' bias-corrected step size lr * sqrt(1 - b2^t) / (1 - b1^t) in float32 as the entry points above compute it from
+ * (t, lr, b1, b2) -- for a caller that keeps the values of steps 1..n in a device table. */
+float rec_adam_lr_t_f32(float lr, float b1, float b2, int64_t t);
+/* Device-side step counter: *step_dev += 1, *lr_t_dev = lr_table[min(*step_dev, n_table) - 1] (one tiny launch).  With it
+ * a train step holds no per-step host scalar and can be captured in a hipGraph. */
+int rec_adam_advance_f32(int64_t* step_dev, const float* lr_table, int64_t n_table, float* lr_t_dev, void* stream);
+/* rec_adam_dense_f32 on up to 16 parameters in ONE launch, step size read from device memory (host arrays of device
+ * pointers, copied into the kernel arguments). */
+int rec_adam_dense_multi_f32(int n_tensors, float* const* var, float* const* m, float* const* v, const float* const* g,
+                             const int64_t* numel, const float* lr_t_dev, float b1, float b2, float eps, void* stream);
 /* Keras sparse apply = DENSE SWEEP: m*=b1, v*=b2 on all V rows, m[ids]+=(1-b1)g, v[ids]+=(1-b2)g^2, then
  * var -= lr_t*m/(sqrt(v)+eps) on all V rows.  (uniq_ids, g_rows, n_uniq) as produced by the dedup above
  * (cap = allocated rows of uniq_ids/g_rows).  var has row stride ld; m, v are dense [V,E].
@@ -333,6 +343,14 @@ int rec_deepfm_fused_post_direct_adam_f32(int F, int64_t B, const float* gz, con
                                           float* g_embed_rows, float* g_w_rows, int64_t* n_uniq, float* table, int64_t ld,
                                           int64_t V, float* m_e, float* v_e, float* m_w, float* v_w, int64_t t, float lr,
                                           float b1, float b2, float eps, void* stream);
+/* ... the same with the step size read from device memory (rec_adam_advance_f32 on the same stream). */
+int rec_deepfm_fused_post_direct_adam_dev_f32(int F, int64_t B, const float* gz, const float* vals, float* dK0, float* db0,
+                                              float* dK1, float* db1, float* dK2, float* db2, float* dbias, float* loss,
+                                              void* workspace, const int32_t* perm, const int64_t* col_uid,
+                                              const int32_t* col_seg, const int32_t* col_nu, int64_t* uniq_ids,
+                                              float* g_embed_rows, float* g_w_rows, int64_t* n_uniq, float* table,
+                                              int64_t ld, int64_t V, float* m_e, float* v_e, float* m_w, float* v_w,
+                                              const float* lr_t_dev, float b1, float b2, float eps, void* stream);
 /* segment sums of vals [B*F,16] (embed) and gz [B] (w) over that plan + compaction to the global ascending list:
  * uniq_ids [B*F], g_embed_rows [B*F,16], g_w_rows [B*F], n_uniq; the tail is padded like rec_dedup_plan_i64's. */
 int rec_colseg_sum_f32(const float* vals, const float* gz, const int32_t* perm, const int64_t* col_uid,

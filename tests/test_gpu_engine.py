@@ -371,6 +371,33 @@ def test_fused_step_lazy_adam_in_post_launch(dist):
     assert (a.state["w.embeddings"][1] - b.state["w.embeddings"][1]).abs().max().item() <= 1e-6
 
 
+def test_fused_lazy_adam_train_steps_replayed_from_graphs_equal_eager_ones():
+    """The whole train step with the lazy Adam inside the post launch holds no per-step host scalar (the step counter and
+    the bias-corrected step size live on the device), so cycles of steps are captured and replayed: parameters and
+    optimizer state after 12 steps -- first calls enqueued eagerly and captured, later ones replayed -- must equal the
+    eagerly enqueued steps bit for bit."""
+    from explicit_tf2_recommendation_amd import engine, data
+    B, F, V = 1024, 26, 30000
+    la, names, gen = make16(B, F, V, 37, "zipf")
+    lb, _, _ = make16(B, F, V, 37, "zipf")
+    lb.load_state_dict(la.state_dict())
+    a = engine.DeepFMFusedStep(la, B, gen.dims, gen.offsets, optimizer="lazy_adam", lr=0.01, use_graph=False)
+    b = engine.DeepFMFusedStep(lb, B, gen.dims, gen.offsets, optimizer="lazy_adam", lr=0.01, use_graph=True)
+    batches = [data.to_device(gen.batch(B)) for _ in range(4)]
+    for rep in range(3):                                     # the same two calls three times: capture, then replays
+        for lo in (0, 2):
+            cur, nxt = batches[lo:lo + 2], batches[(lo + 2) % 4:(lo + 2) % 4 + 2]
+            la_loss = a.many(cur, then=nxt).item()
+            lb_loss = b.many(cur, then=nxt).item()
+            assert la_loss == lb_loss, (rep, lo)
+    assert a.t == b.t == 12 and int(b._step_dev.item()) == 12
+    for (k, p), (_, q) in zip(la.named_parameters(), lb.named_parameters()):
+        assert torch.equal(p, q), k
+    for k in a.state:
+        assert torch.equal(a.state[k][0], b.state[k][0]) and torch.equal(a.state[k][1], b.state[k][1]), k
+    assert len(b._graphs) >= 2 and len(a._graphs) == 0
+
+
 @pytest.mark.parametrize("family", ["dssm", "dcn_matrix", "dcn_vec", "din"])
 def test_graphed_train_step_equals_eager_autograd(family):
     """engine.GraphedTrainStep: forward + KerasBCE + autograd backward replayed from one hipGraph must give the eager
