@@ -448,7 +448,8 @@ def main():
                     st3.many(cur, then=nxt)
 
             lazy_run(2 * n_batches)                               # captures the graphs of the resident batches
-            lazy_run(nl)
+            lazy_run(nl)                                          # ... and of the timed sequence itself, twice: the
+            lazy_run(nl)                                          # plan-buffer ring has two halves
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             lazy_run(nl)
