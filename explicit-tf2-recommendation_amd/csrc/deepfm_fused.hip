@@ -789,6 +789,10 @@ struct ColSegArgs {
   // bias-corrected step size of the lazy Adam read from device memory (set by rec_adam_advance_f32): the train step then
   // holds no per-step host scalar and can be replayed from a hipGraph; null = lr_t above
   const float* lr_t_dev;
+  // row strides (floats) of m_e / v_e and of m_w / v_w: 16 and 1 for dense state arrays; 32 and 32 when the state is
+  // packed beside the rows ([m 16 | v 16] in one 128-byte row, m_w / v_w in the padding of the table row) so that a
+  // touched row costs two line requests instead of five or six
+  int64_t ldm, ldw;
 };
 
 // m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2 ; var <- var - lr_t m / (sqrt(v) + eps)   (rec_adam_rows_f32's formula)
@@ -800,8 +804,8 @@ __device__ __forceinline__ void adam_elem(float& var, float& m, float& v, float 
 }
 __device__ __forceinline__ void adam_chunk(const ColSegArgs& k, int64_t id, int c, const float4& g) {
   float4* vp = reinterpret_cast<float4*>(k.table + id * LD) + c;
-  float4* mp = reinterpret_cast<float4*>(k.m_e + id * E16) + c;
-  float4* qp = reinterpret_cast<float4*>(k.v_e + id * E16) + c;
+  float4* mp = reinterpret_cast<float4*>(k.m_e + id * k.ldm) + c;
+  float4* qp = reinterpret_cast<float4*>(k.v_e + id * k.ldm) + c;
   float4 x = *vp, m = *mp, v = *qp;
   adam_elem(x.x, m.x, v.x, g.x, k.lr_t, k.b1, k.b2, k.eps);
   adam_elem(x.y, m.y, v.y, g.y, k.lr_t, k.b1, k.b2, k.eps);
@@ -810,9 +814,9 @@ __device__ __forceinline__ void adam_chunk(const ColSegArgs& k, int64_t id, int 
   *vp = x; *mp = m; *qp = v;
 }
 __device__ __forceinline__ void adam_w(const ColSegArgs& k, int64_t id, float g) {
-  float x = k.table[id * LD + E16], m = k.m_w[id], v = k.v_w[id];
+  float x = k.table[id * LD + E16], m = k.m_w[id * k.ldw], v = k.v_w[id * k.ldw];
   adam_elem(x, m, v, g, k.lr_t, k.b1, k.b2, k.eps);
-  k.table[id * LD + E16] = x; k.m_w[id] = m; k.v_w[id] = v;
+  k.table[id * LD + E16] = x; k.m_w[id * k.ldw] = m; k.v_w[id * k.ldw] = v;
 }
 
 __device__ __forceinline__ void colseg_body(const ColSegArgs& k, int bidx) {
@@ -1220,6 +1224,7 @@ static int launch_post(bool direct, int F, int64_t B, const float* gz, const flo
   } else if (adam) {
     k.table = adam->table; k.m_e = adam->m_e; k.v_e = adam->v_e; k.m_w = adam->m_w; k.v_w = adam->v_w; k.V = adam->V;
     k.lr_t = adam->lr_t; k.b1 = adam->b1; k.b2 = adam->b2; k.eps = adam->eps; k.lr_t_dev = adam->lr_t_dev;
+    k.ldm = adam->ldm ? adam->ldm : E16; k.ldw = adam->ldw ? adam->ldw : 1;
   }
   if (direct) {
     unsigned nbf = (unsigned)F * (unsigned)ceil_div64(B, FIX_T);
@@ -1317,15 +1322,18 @@ extern "C" int rec_deepfm_fused_post_direct_adam_dev_f32(int F, int64_t B, const
                                                          const int32_t* col_nu, int64_t* uniq_ids, float* g_embed_rows,
                                                          float* g_w_rows, int64_t* n_uniq, float* table, int64_t ld,
                                                          int64_t V, float* m_e, float* v_e, float* m_w, float* v_w,
+                                                         int64_t ld_state, int64_t ld_wstate,
                                                          const float* lr_t_dev, float b1, float b2, float eps,
                                                          void* stream) {
-  if (!table || !m_e || !v_e || !m_w || !v_w || !lr_t_dev || V <= 0) return REC_E_ARG;
+  if (!table || !m_e || !v_e || !m_w || !v_w || !lr_t_dev || V <= 0 || ld_state < E16 || (ld_state & 3) != 0 ||
+      ld_wstate < 1)
+    return REC_E_ARG;
   if (ld != LD || (reinterpret_cast<uintptr_t>(table) & 15) != 0 || (reinterpret_cast<uintptr_t>(m_e) & 15) != 0 ||
       (reinterpret_cast<uintptr_t>(v_e) & 15) != 0)
     return REC_E_UNSUPPORTED;
   ColSegArgs a{};
   a.table = table; a.m_e = m_e; a.v_e = v_e; a.m_w = m_w; a.v_w = v_w; a.V = V;
-  a.lr_t = 0.f; a.lr_t_dev = lr_t_dev; a.b1 = b1; a.b2 = b2; a.eps = eps;
+  a.lr_t = 0.f; a.lr_t_dev = lr_t_dev; a.b1 = b1; a.b2 = b2; a.eps = eps; a.ldm = ld_state; a.ldw = ld_wstate;
   return launch_post(true, F, B, gz, vals, dK0, db0, dK1, db1, dK2, db2, dbias, loss, workspace, perm, col_uid, col_seg,
                      col_nu, uniq_ids, g_embed_rows, g_w_rows, n_uniq, 0, stream, &a);
 }

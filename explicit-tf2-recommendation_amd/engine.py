@@ -349,6 +349,15 @@ class DeepFMFusedStep:
             self.side_e = torch.empty((n, 3, 16), **f32)
             self.side_w = torch.empty((n, 3, 1), **f32)
         if self._fused_lazy():
+            # optimizer state packed beside the rows: [m 16 | v 16] of a row is ONE 128-byte line, m_w / v_w live in
+            # floats 17 / 18 of the fused table row (its padding) -- a touched row costs two line requests instead of
+            # five or six (table row, m_e, v_e, m_w, v_w).  state[...] stays a pair of (strided) views
+            fused = getattr(layer, "_fused_storage", None)
+            if fused is not None and fused.shape[1] == 32:
+                self._mv = torch.zeros((self.V, 32), **f32)
+                fused[:, 17:19].zero_()
+                self.state["embed.embeddings"] = (self._mv[:, :16], self._mv[:, 16:])
+                self.state["w.embeddings"] = (fused[:, 17:18], fused[:, 18:19])
             # the step counter and the bias-corrected step size live on the device (rec_adam_advance_f32): the train step
             # holds no per-step host scalar, so it is captured and replayed like the gradient-only step.  The table holds
             # lr_t of steps 1..N exactly as the host-side entry points compute it; beyond it the corrections are 1.0f
@@ -422,7 +431,8 @@ class DeepFMFusedStep:
                 _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(self.loss), _p(self.ws), _p(pl["perm"]),
                 _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.uniq_ids), _p(self.g_embed_rows),
                 _p(self.g_w_rows), _p(self.n_uniq), _p(pe), pe.stride(0), self.V, _p(me), _p(ve), _p(mw), _p(vw),
-                _p(self._lr_t_dev), 0.9, 0.999, 1e-7, st), "rec_deepfm_fused_post_direct_adam_dev_f32")
+                me.stride(0), mw.stride(0), _p(self._lr_t_dev), 0.9, 0.999, 1e-7, st),
+                "rec_deepfm_fused_post_direct_adam_dev_f32")
             return
         if not self.direct:
             check(lib.rec_deepfm_fused_post_f32(

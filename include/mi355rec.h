@@ -343,14 +343,18 @@ int rec_deepfm_fused_post_direct_adam_f32(int F, int64_t B, const float* gz, con
                                           float* g_embed_rows, float* g_w_rows, int64_t* n_uniq, float* table, int64_t ld,
                                           int64_t V, float* m_e, float* v_e, float* m_w, float* v_w, int64_t t, float lr,
                                           float b1, float b2, float eps, void* stream);
-/* ... the same with the step size read from device memory (rec_adam_advance_f32 on the same stream). */
+/* ... the same with the step size read from device memory (rec_adam_advance_f32 on the same stream) and explicit row
+ * strides of the optimizer state: ld_state (floats) for m_e / v_e, ld_wstate for m_w / v_w -- 16 and 1 for dense arrays,
+ * 32 and 32 for state packed beside the rows ([m 16 | v 16] as one 128-byte row, m_w / v_w in the padding of the fused
+ * table row: a touched row then costs two line requests instead of five or six). */
 int rec_deepfm_fused_post_direct_adam_dev_f32(int F, int64_t B, const float* gz, const float* vals, float* dK0, float* db0,
                                               float* dK1, float* db1, float* dK2, float* db2, float* dbias, float* loss,
                                               void* workspace, const int32_t* perm, const int64_t* col_uid,
                                               const int32_t* col_seg, const int32_t* col_nu, int64_t* uniq_ids,
                                               float* g_embed_rows, float* g_w_rows, int64_t* n_uniq, float* table,
                                               int64_t ld, int64_t V, float* m_e, float* v_e, float* m_w, float* v_w,
-                                              const float* lr_t_dev, float b1, float b2, float eps, void* stream);
+                                              int64_t ld_state, int64_t ld_wstate, const float* lr_t_dev, float b1,
+                                              float b2, float eps, void* stream);
 /* segment sums of vals [B*F,16] (embed) and gz [B] (w) over that plan + compaction to the global ascending list:
  * uniq_ids [B*F], g_embed_rows [B*F,16], g_w_rows [B*F], n_uniq; the tail is padded like rec_dedup_plan_i64's. */
 int rec_colseg_sum_f32(const float* vals, const float* gz, const int32_t* perm, const int64_t* col_uid,
