@@ -655,9 +655,7 @@ extern "C" int rec_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
     REC_LAUNCH_CHECK();
     return REC_OK;
   }
-  // row panels x all N: a tall product with a modest N and row-major A (CrossNet matrix mode and its dX, split_k = 1), or
-  // its weight gradient H^T.X (A k-major, M and N modest, K = batch): there the panels are multiplied by K slices so
-  // that every CU gets one workgroup, and the slices are added in order
+  // row panels x all N: a tall product with a modest N and row-major A (CrossNet matrix mode and its dX, split_k = 1)
   // ... or a wider N in several column panels when K is short (the A panel is then cheap to read once per column panel)
   const int64_t ncol_panels = N <= PNB * 32 ? 1 : ceil_div64(N, PNB * 32);
   const int64_t ncp = ncol_panels == 1 ? 0 : ((ceil_div64(N, ncol_panels) + 31) / 32) * 32;
@@ -666,24 +664,16 @@ extern "C" int rec_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
                           (ncol_panels > 1 && ncol_panels <= 64 && K <= 256 && ceil_div64(M, 64) * ncol_panels >= 192));
   // (measured and not taken: M = N = 835, K = 16384 as 14 panels x 19 K slices ran 456 us against 358 us on the 128x128
   // split-K tiles -- every slice's 2.9 MB of X is fetched by the L2 of each of the 8 XCDs its 14 panels land on)
-  const bool panel_wg = false;
-  if (panel_fwd || panel_wg) {
+  if (panel_fwd) {
     const int maxb = (int)ceil_div64(ceil_div64(ncp > 0 ? ncp : N, 32), 4);   // column blocks per wave, 1..7
     constexpr int PMt = 64, PKt = 16;
     const size_t lds = sizeof(float) * (2 * PKt * (PMt + PPAD) + 2 * PKt * ((size_t)maxb * 128 + PPAD));
     const int64_t panels = ceil_div64(M, PMt);
-    int psplit = 1;
-    int64_t pchunk = K;
+    // (the kernel can also take K slices of a k-major A -- blockIdx.y, partials in ws -- for the weight gradient H^T.X;
+    // measured slower than the 128x128 split-K tiles, see above, so no slice is ever launched from here)
+    const int psplit = 1;
+    const int64_t pchunk = K;
     float* pws = nullptr;
-    if (panel_wg) {
-      psplit = split_k;                              // the caller's (ops.split_k_for: ~ one workgroup per CU)
-      pchunk = ((ceil_div64(K, psplit) + PKt - 1) / PKt) * PKt;
-      psplit = (int)ceil_div64(K, pchunk);
-      if (psplit > 1) {
-        if (!workspace || psplit > split_k) return REC_E_WORKSPACE;    // the caller sizes ws for split_k slices
-        pws = workspace;
-      }
-    }
     dim3 grid((unsigned)panels, (unsigned)psplit, (unsigned)ncol_panels);
 #define PANEL(TAv, TBv, MB)                                                                                          \
   do {                                                                                                               \
@@ -703,15 +693,10 @@ extern "C" int rec_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_
     case 6: PANEL(TAv, TBv, 6); break;                                                                               \
     default: PANEL(TAv, TBv, 7); break;                                                                              \
   }
-    if (panel_wg) { PANEL_MB(1, 0); } else if (transB) { PANEL_MB(0, 1); } else { PANEL_MB(0, 0); }
+    if (transB) { PANEL_MB(0, 1); } else { PANEL_MB(0, 0); }
 #undef PANEL_MB
 #undef PANEL
     REC_LAUNCH_CHECK();
-    if (pws) {
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div64(M * N, 256)), dim3(256), 0, st, pws, psplit, M,
-                         N, C, ldc, epilogue_kind, bias, e0, lde0, e1, lde1, aux);
-      REC_LAUNCH_CHECK();
-    }
     return REC_OK;
   }
   if (big) {
