@@ -43,7 +43,9 @@ SIGNATURES = {
     "rec_adam_advance_f32": (i32, [p, p, i64, p, p]),
     "rec_adam_dense_multi_f32": (i32, [i32, p, p, p, p, p, p, f32, f32, f32, p]),
     "rec_deepfm_fused_post_direct_adam_dev_f32": (i32, [i32, i64] + [p] * 19 + [p, i64, i64, p, p, p, p, i64, i64, p, f32,
-                                                                           f32, f32, p]),
+                                                                           f32, f32, p, p, p]),
+    "rec_adam_keras_catchup_f32": (i32, [p, p, i64, i32, p, i64, i64, p, p, i64, p, p, i64, p, p, p, i64, f32, f32, f32, p]),
+    "rec_adam_keras_flush_f32": (i32, [p, i64, i64, p, p, i64, p, p, i64, p, p, p, i64, f32, f32, f32, p]),
     "rec_adam_dense_f32": (i32, [p, p, p, p, i64, i64, f32, f32, f32, f32, p]),
     "rec_adam_sparse_keras_f32": (i32, [p, i64, p, p, i64, i32, p, p, p, i64, p, i64, f32, f32, f32, f32, p]),
     "rec_adam_sparse_keras_pair_f32": (i32, [p, i64, p, p, p, p, i64, i32, p, p, p, p, i64, p, p, i64, f32, f32, f32, f32, p]),

@@ -44,3 +44,34 @@ __device__ __forceinline__ float row16_allsum(float v) {
   return v;
 }
 
+
+// Keras Adam on one element with the operation sequence pinned: every multiply-add is an EXPLICIT fma (the compiler may
+// fuse `a*b + c` or not, differently in every kernel; an explicit fma it can only keep) and what is left offers nothing to
+// fuse.  Every kernel that applies a step -- the dense sweep, the touched-row kernels, the update inside the fused post
+// launch, the catch-up of lazily evaluated rows -- therefore produces the same bits:
+//   touched   m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2 ; x <- x - lr_t m / (sqrt(v) + eps)
+//   untouched m <- b1 m            ; v <- b2 v              ; x <- x - lr_t m / (sqrt(v) + eps)   (Keras' dense sweep)
+__device__ __forceinline__ float adam_step_x(float x, float m, float v, float lr_t, float eps) {
+  const float num = lr_t * m;                        // a product that feeds a division: nothing to fuse
+  const float den = sqrtf(v) + eps;
+  return x - num / den;
+}
+__device__ __forceinline__ void adam_touch(float& x, float& m, float& v, float g, float lr_t, float b1, float b2,
+                                           float eps) {
+  m = __builtin_fmaf(g, 1.f - b1, m * b1);
+  v = __builtin_fmaf(g * g, 1.f - b2, v * b2);
+  x = adam_step_x(x, m, v, lr_t, eps);
+}
+// dense parameters (Keras' dense apply): m <- m + (g - m)(1 - b1) ; v <- v + (g^2 - v)(1 - b2)
+__device__ __forceinline__ void adam_dense_elem(float& x, float& m, float& v, float g, float lr_t, float b1, float b2,
+                                                float eps) {
+  m = __builtin_fmaf(g - m, 1.f - b1, m);
+  v = __builtin_fmaf(__builtin_fmaf(g, g, -v), 1.f - b2, v);
+  x = adam_step_x(x, m, v, lr_t, eps);
+}
+__device__ __forceinline__ void adam_decay(float& x, float& m, float& v, float lr_t, float b1, float b2, float eps) {
+  m = m * b1;
+  v = v * b2;
+  x = adam_step_x(x, m, v, lr_t, eps);
+}
+

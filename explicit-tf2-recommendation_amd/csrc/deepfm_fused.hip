@@ -793,14 +793,15 @@ struct ColSegArgs {
   // packed beside the rows ([m 16 | v 16] in one 128-byte row, m_w / v_w in the padding of the table row) so that a
   // touched row costs two line requests instead of five or six
   int64_t ldm, ldw;
+  // exact lazy evaluation of Keras' dense sweep (rec_adam_keras_catchup_f32): last[row] = the step whose update the row
+  // holds; a touched row holds step *step_dev afterwards.  null: plain touched-rows Adam
+  int32_t* last; const int64_t* step_dev;
 };
 
 // m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2 ; var <- var - lr_t m / (sqrt(v) + eps)   (rec_adam_rows_f32's formula)
 __device__ __forceinline__ void adam_elem(float& var, float& m, float& v, float g, float lr_t, float b1, float b2,
                                           float eps) {
-  m = m * b1 + g * (1.f - b1);
-  v = v * b2 + g * g * (1.f - b2);
-  var = var - lr_t * m / (sqrtf(v) + eps);
+  adam_touch(var, m, v, g, lr_t, b1, b2, eps);       // common.h: rounding pinned, the same bits in every kernel
 }
 __device__ __forceinline__ void adam_chunk(const ColSegArgs& k, int64_t id, int c, const float4& g) {
   float4* vp = reinterpret_cast<float4*>(k.table + id * LD) + c;
@@ -985,6 +986,7 @@ __device__ __forceinline__ void fixup_body(const ColSegArgs& k_in, int bidx) {
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) adam_chunk(k, id, cc, g_embed[dst * 4 + cc]);
       adam_w(k, id, accw);
+      if (k.last) k.last[id] = (int32_t)*k.step_dev;
     }
     if (len > 1 && len <= 8) {                                  // short run: this lane alone
       float4 a0 = g_embed[dst * 4], a1 = g_embed[dst * 4 + 1], a2 = g_embed[dst * 4 + 2], a3 = g_embed[dst * 4 + 3];
@@ -1002,6 +1004,7 @@ __device__ __forceinline__ void fixup_body(const ColSegArgs& k_in, int bidx) {
       if (adam && (uint64_t)id < (uint64_t)k.V) {
         adam_chunk(k, id, 0, a0); adam_chunk(k, id, 1, a1); adam_chunk(k, id, 2, a2); adam_chunk(k, id, 3, a3);
         adam_w(k, id, accw);
+        if (k.last) k.last[id] = (int32_t)*k.step_dev;
       }
     }
     if (len <= 8) k.g_w[dst] = accw;
@@ -1048,7 +1051,10 @@ __device__ __forceinline__ void fixup_body(const ColSegArgs& k_in, int bidx) {
         const int64_t rid = k.col_uid[(int64_t)f * B + ru];
         if ((uint64_t)rid < (uint64_t)k.V) {
           adam_chunk(k, rid, c, h);
-          if (c == 0) adam_w(k, rid, wsum);
+          if (c == 0) {
+            adam_w(k, rid, wsum);
+            if (k.last) k.last[rid] = (int32_t)*k.step_dev;
+          }
         }
       }
     }
@@ -1066,6 +1072,49 @@ __global__ __launch_bounds__(1024) void deepfm_post_direct_kernel(ReduceArgs r, 
 __global__ __launch_bounds__(1024) void deepfm_post_kernel(ReduceArgs r, ColSegArgs k, int nb_reduce) {
   if ((int)blockIdx.x < nb_reduce) reduce_body(r, (int)blockIdx.x);
   else colseg_body(k, (int)blockIdx.x - nb_reduce);
+}
+
+
+// ---- Keras Adam, evaluated lazily AND exactly.  Keras' sparse apply is a dense sweep: every row of the table decays its
+// moments and moves every step (2.FM/ModelManager.py:178-179 on IndexedSlices gradients).  The update of an untouched row
+// at step j depends on nothing but the row and lr_j, so a row may skip the sweeps and REPLAY them later: last[row] = the
+// step the row holds, and before a batch reads its rows this kernel applies the steps last+1 .. *step_dev they missed,
+// element by element with the sweep's own arithmetic (adam_decay) -- the same bits the sweep would have left.  The rows
+// of a batch then receive the touched update of the current step in the post launch, which also sets last.
+// Threads: 16 per unique id of the batch's plan (one embed element each), then one per id for the w element.
+struct CatchArgs {
+  const int64_t* col_uid; const int32_t* col_nu; int64_t B; int F;   // plan of the batch; null col_uid: all rows [0, V)
+  float* table; int64_t V; float* m_e; float* v_e; int64_t ldm; float* m_w; float* v_w; int64_t ldw;
+  const int32_t* last; const int64_t* step_dev; const float* lr_tab; int64_t n_tab; float b1, b2, eps;
+};
+__global__ __launch_bounds__(256) void adam_keras_catchup_kernel(CatchArgs a) {
+  const int64_t nslot = a.col_uid ? a.B * a.F : a.V;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool is_w = t >= nslot * E16;
+  const int64_t slot = is_w ? t - nslot * E16 : t >> 4;
+  if (slot >= nslot) return;
+  int64_t id = slot;
+  if (a.col_uid) {
+    const int f = (int)(slot / a.B);
+    const int64_t u = slot - (int64_t)f * a.B;
+    if (u >= a.col_nu[f]) return;
+    id = a.col_uid[(int64_t)f * a.B + u];
+    if ((uint64_t)id >= (uint64_t)a.V) return;
+  }
+  const int64_t j0 = a.last[id], j1 = *a.step_dev;
+  if (j0 >= j1) return;
+  float* px = is_w ? a.table + id * LD + E16 : a.table + id * LD + (t & 15);
+  float* pm = is_w ? a.m_w + id * a.ldw : a.m_e + id * a.ldm + (t & 15);
+  float* pv = is_w ? a.v_w + id * a.ldw : a.v_e + id * a.ldm + (t & 15);
+  float x = *px, m = *pm, v = *pv;
+  if (m == 0.f && v == 0.f) return;                    // x - lr*0/(0+eps) = x: a row that was never touched stays put
+  for (int64_t j = j0 + 1; j <= j1; ++j) adam_decay(x, m, v, a.lr_tab[(j < a.n_tab ? j : a.n_tab) - 1], a.b1, a.b2, a.eps);
+  *px = x; *pm = m; *pv = v;
+}
+__global__ __launch_bounds__(256) void fill_last_kernel(int32_t* __restrict__ last, int64_t V,
+                                                        const int64_t* __restrict__ step_dev) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < V) last[t] = (int32_t)*step_dev;
 }
 
 }  // namespace
@@ -1225,6 +1274,7 @@ static int launch_post(bool direct, int F, int64_t B, const float* gz, const flo
     k.table = adam->table; k.m_e = adam->m_e; k.v_e = adam->v_e; k.m_w = adam->m_w; k.v_w = adam->v_w; k.V = adam->V;
     k.lr_t = adam->lr_t; k.b1 = adam->b1; k.b2 = adam->b2; k.eps = adam->eps; k.lr_t_dev = adam->lr_t_dev;
     k.ldm = adam->ldm ? adam->ldm : E16; k.ldw = adam->ldw ? adam->ldw : 1;
+    k.last = adam->last; k.step_dev = adam->step_dev;
   }
   if (direct) {
     unsigned nbf = (unsigned)F * (unsigned)ceil_div64(B, FIX_T);
@@ -1324,7 +1374,7 @@ extern "C" int rec_deepfm_fused_post_direct_adam_dev_f32(int F, int64_t B, const
                                                          int64_t V, float* m_e, float* v_e, float* m_w, float* v_w,
                                                          int64_t ld_state, int64_t ld_wstate,
                                                          const float* lr_t_dev, float b1, float b2, float eps,
-                                                         void* stream) {
+                                                         int32_t* last, const int64_t* step_dev, void* stream) {
   if (!table || !m_e || !v_e || !m_w || !v_w || !lr_t_dev || V <= 0 || ld_state < E16 || (ld_state & 3) != 0 ||
       ld_wstate < 1)
     return REC_E_ARG;
@@ -1333,9 +1383,55 @@ extern "C" int rec_deepfm_fused_post_direct_adam_dev_f32(int F, int64_t B, const
     return REC_E_UNSUPPORTED;
   ColSegArgs a{};
   a.table = table; a.m_e = m_e; a.v_e = v_e; a.m_w = m_w; a.v_w = v_w; a.V = V;
+  if (last && !step_dev) return REC_E_ARG;
   a.lr_t = 0.f; a.lr_t_dev = lr_t_dev; a.b1 = b1; a.b2 = b2; a.eps = eps; a.ldm = ld_state; a.ldw = ld_wstate;
+  a.last = last; a.step_dev = step_dev;
   return launch_post(true, F, B, gz, vals, dK0, db0, dK1, db1, dK2, db2, dbias, loss, workspace, perm, col_uid, col_seg,
                      col_nu, uniq_ids, g_embed_rows, g_w_rows, n_uniq, 0, stream, &a);
+}
+
+static int catchup_args_ok(const float* table, int64_t ld, int64_t V, const float* m_e, const float* v_e, int64_t ld_state,
+                           const float* m_w, const float* v_w, int64_t ld_wstate, const int32_t* last,
+                           const int64_t* step_dev, const float* lr_table, int64_t n_table) {
+  if (!table || !m_e || !v_e || !m_w || !v_w || !last || !step_dev || !lr_table || V <= 0 || n_table <= 0 ||
+      ld_state < E16 || ld_wstate < 1)
+    return REC_E_ARG;
+  if (ld != LD) return REC_E_UNSUPPORTED;
+  return REC_OK;
+}
+
+extern "C" int rec_adam_keras_catchup_f32(const int64_t* col_uid, const int32_t* col_nu, int64_t B, int F, float* table,
+                                          int64_t ld, int64_t V, float* m_e, float* v_e, int64_t ld_state, float* m_w,
+                                          float* v_w, int64_t ld_wstate, const int32_t* last, const int64_t* step_dev,
+                                          const float* lr_table, int64_t n_table, float b1, float b2, float eps,
+                                          void* stream) {
+  if (!col_uid || !col_nu || B <= 0 || F <= 0) return REC_E_ARG;
+  int rc = catchup_args_ok(table, ld, V, m_e, v_e, ld_state, m_w, v_w, ld_wstate, last, step_dev, lr_table, n_table);
+  if (rc != REC_OK) return rc;
+  CatchArgs a{col_uid, col_nu, B, F, table, V, m_e, v_e, ld_state, m_w, v_w, ld_wstate, last, step_dev, lr_table, n_table,
+              b1, b2, eps};
+  hipLaunchKernelGGL(adam_keras_catchup_kernel, dim3((unsigned)ceil_div64(B * F * (E16 + 1), 256)), dim3(256), 0,
+                     as_stream(stream), a);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+// every row of the table up to date (before the parameters are read from outside: evaluation, checkpoint), last = step
+extern "C" int rec_adam_keras_flush_f32(float* table, int64_t ld, int64_t V, float* m_e, float* v_e, int64_t ld_state,
+                                        float* m_w, float* v_w, int64_t ld_wstate, int32_t* last, const int64_t* step_dev,
+                                        const float* lr_table, int64_t n_table, float b1, float b2, float eps,
+                                        void* stream) {
+  int rc = catchup_args_ok(table, ld, V, m_e, v_e, ld_state, m_w, v_w, ld_wstate, last, step_dev, lr_table, n_table);
+  if (rc != REC_OK) return rc;
+  CatchArgs a{nullptr, nullptr, 0, 0, table, V, m_e, v_e, ld_state, m_w, v_w, ld_wstate, last, step_dev, lr_table,
+              n_table, b1, b2, eps};
+  hipLaunchKernelGGL(adam_keras_catchup_kernel, dim3((unsigned)ceil_div64(V * (E16 + 1), 256)), dim3(256), 0,
+                     as_stream(stream), a);
+  REC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(fill_last_kernel, dim3((unsigned)ceil_div64(V, 256)), dim3(256), 0, as_stream(stream), last, V,
+                     step_dev);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
 }
 
 extern "C" size_t rec_colsort_workspace_bytes(int64_t B, int F) {

@@ -456,13 +456,11 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ var
                                                          float lr_t, float b1, float b2, float eps) {
   int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n) return;
-  float gg = g[t];
-  float mm = m[t], vv = v[t];
-  mm = mm + (gg - mm) * (1.f - b1);
-  vv = vv + (gg * gg - vv) * (1.f - b2);
+  float xx = var[t], mm = m[t], vv = v[t];
+  adam_dense_elem(xx, mm, vv, g[t], lr_t, b1, b2, eps);
   m[t] = mm;
   v[t] = vv;
-  var[t] = var[t] - lr_t * mm / (sqrtf(vv) + eps);
+  var[t] = xx;
 }
 
 // touched rows: new (var, m, v) computed from the ORIGINAL state into `side` [cap, 3, E]
@@ -479,10 +477,9 @@ __global__ __launch_bounds__(256) void adam_rows_side_kernel(const float* __rest
   if (u >= *n_uniq) return;
   int64_t id = ids[u];
   if ((uint64_t)id >= (uint64_t)V) return;
-  float gg = g[t];
-  float mm = m[id * E + d] * b1 + gg * (1.f - b1);
-  float vv = v[id * E + d] * b2 + gg * gg * (1.f - b2);
-  side[(u * 3 + 0) * E + d] = var[id * ld + d] - lr_t * mm / (sqrtf(vv) + eps);
+  float xx = var[id * ld + d], mm = m[id * E + d], vv = v[id * E + d];
+  adam_touch(xx, mm, vv, g[t], lr_t, b1, b2, eps);
+  side[(u * 3 + 0) * E + d] = xx;
   side[(u * 3 + 1) * E + d] = mm;
   side[(u * 3 + 2) * E + d] = vv;
 }
@@ -499,12 +496,10 @@ __global__ __launch_bounds__(256) void adam_sweep_vec_kernel(float* __restrict__
     int c = (int)(t - r * lpr);
     float4* xp = reinterpret_cast<float4*>(var + r * ld + 4 * c);
     float4 mm = m[t], vv = v[t], x = *xp;
-    mm.x *= b1; mm.y *= b1; mm.z *= b1; mm.w *= b1;
-    vv.x *= b2; vv.y *= b2; vv.z *= b2; vv.w *= b2;
-    x.x -= lr_t * mm.x / (sqrtf(vv.x) + eps);
-    x.y -= lr_t * mm.y / (sqrtf(vv.y) + eps);
-    x.z -= lr_t * mm.z / (sqrtf(vv.z) + eps);
-    x.w -= lr_t * mm.w / (sqrtf(vv.w) + eps);
+    adam_decay(x.x, mm.x, vv.x, lr_t, b1, b2, eps);
+    adam_decay(x.y, mm.y, vv.y, lr_t, b1, b2, eps);
+    adam_decay(x.z, mm.z, vv.z, lr_t, b1, b2, eps);
+    adam_decay(x.w, mm.w, vv.w, lr_t, b1, b2, eps);
     m[t] = mm;
     v[t] = vv;
     *xp = x;
@@ -519,10 +514,11 @@ __global__ __launch_bounds__(256) void adam_sweep_scalar_kernel(float* __restric
   for (; t < n; t += stride) {
     int64_t r = t / E;
     int d = (int)(t - r * E);
-    float mm = m[t] * b1, vv = v[t] * b2;
+    float mm = m[t], vv = v[t], xx = var[r * ld + d];
+    adam_decay(xx, mm, vv, lr_t, b1, b2, eps);
     m[t] = mm;
     v[t] = vv;
-    var[r * ld + d] = var[r * ld + d] - lr_t * mm / (sqrtf(vv) + eps);
+    var[r * ld + d] = xx;
   }
 }
 
@@ -554,12 +550,11 @@ __global__ __launch_bounds__(256) void adam_rows_lazy_kernel(float* __restrict__
   if (u >= *n_uniq) return;
   int64_t id = ids[u];
   if ((uint64_t)id >= (uint64_t)V) return;
-  float gg = g[t];
-  float mm = m[id * E + d] * b1 + gg * (1.f - b1);
-  float vv = v[id * E + d] * b2 + gg * gg * (1.f - b2);
+  float xx = var[id * ld + d], mm = m[id * E + d], vv = v[id * E + d];
+  adam_touch(xx, mm, vv, g[t], lr_t, b1, b2, eps);
   m[id * E + d] = mm;
   v[id * E + d] = vv;
-  var[id * ld + d] = var[id * ld + d] - lr_t * mm / (sqrtf(vv) + eps);
+  var[id * ld + d] = xx;
 }
 
 // ---- device-side step size: *step += 1, *lr_t = table[min(step, n) - 1].  The table holds Keras' bias-corrected step size
@@ -588,13 +583,11 @@ __global__ __launch_bounds__(256) void adam_dense_multi_kernel(AdamMulti a, cons
   while (t >= a.end[i]) ++i;
   const int64_t e = t - (i ? a.end[i - 1] : 0);
   const float lr_t = *lr_t_dev;
-  float gg = a.g[i][e];
-  float mm = a.m[i][e], vv = a.v[i][e];
-  mm = mm + (gg - mm) * (1.f - b1);
-  vv = vv + (gg * gg - vv) * (1.f - b2);
+  float xx = a.var[i][e], mm = a.m[i][e], vv = a.v[i][e];
+  adam_dense_elem(xx, mm, vv, a.g[i][e], lr_t, b1, b2, eps);
   a.m[i][e] = mm;
   a.v[i][e] = vv;
-  a.var[i][e] = a.var[i][e] - lr_t * mm / (sqrtf(vv) + eps);
+  a.var[i][e] = xx;
 }
 
 inline float adam_lr_t(float lr, float b1, float b2, int64_t t) {
@@ -888,21 +881,20 @@ __global__ __launch_bounds__(256) void adam_sweep_pair_kernel(float* __restrict_
       float4* xp = reinterpret_cast<float4*>(base + r * ld + 4 * c);
       int64_t i = r * lpr + c;
       float4 mm = m_e[i], vv = v_e[i], x = *xp;
-      mm.x *= b1; mm.y *= b1; mm.z *= b1; mm.w *= b1;
-      vv.x *= b2; vv.y *= b2; vv.z *= b2; vv.w *= b2;
-      x.x -= lr_t * mm.x / (sqrtf(vv.x) + eps);
-      x.y -= lr_t * mm.y / (sqrtf(vv.y) + eps);
-      x.z -= lr_t * mm.z / (sqrtf(vv.z) + eps);
-      x.w -= lr_t * mm.w / (sqrtf(vv.w) + eps);
+      adam_decay(x.x, mm.x, vv.x, lr_t, b1, b2, eps);
+      adam_decay(x.y, mm.y, vv.y, lr_t, b1, b2, eps);
+      adam_decay(x.z, mm.z, vv.z, lr_t, b1, b2, eps);
+      adam_decay(x.w, mm.w, vv.w, lr_t, b1, b2, eps);
       m_e[i] = mm;
       v_e[i] = vv;
       *xp = x;
     } else {
       float* xp = base + r * ld + 4 * lpr;
-      float mm = m_w[r] * b1, vv = v_w[r] * b2;
+      float mm = m_w[r], vv = v_w[r], xx = *xp;
+      adam_decay(xx, mm, vv, lr_t, b1, b2, eps);
       m_w[r] = mm;
       v_w[r] = vv;
-      *xp = *xp - lr_t * mm / (sqrtf(vv) + eps);
+      *xp = xx;
     }
   }
 }

@@ -358,6 +358,8 @@ class DeepFMFusedStep:
                 fused[:, 17:19].zero_()
                 self.state["embed.embeddings"] = (self._mv[:, :16], self._mv[:, 16:])
                 self.state["w.embeddings"] = (fused[:, 17:18], fused[:, 18:19])
+            self._last = (torch.zeros(self.V, dtype=torch.int32, device=dev)
+                          if optimizer == "keras_adam_lazy" else None)    # the step every row holds
             # the step counter and the bias-corrected step size live on the device (rec_adam_advance_f32): the train step
             # holds no per-step host scalar, so it is captured and replayed like the gradient-only step.  The table holds
             # lr_t of steps 1..N exactly as the host-side entry points compute it; beyond it the corrections are 1.0f
@@ -398,6 +400,14 @@ class DeepFMFusedStep:
         arr = (C.c_void_p * F)(*[c.data_ptr() for c in cols])
         emb = L.embed.embeddings
         pl = self.plans[buf]
+        if self._fused_lazy() and self._last is not None:
+            # Keras Adam, lazily: the rows this batch reads replay the sweeps they skipped (steps last+1 .. now)
+            (me, ve), (mw, vw) = self.state["embed.embeddings"], self.state["w.embeddings"]
+            check(lib.rec_adam_keras_catchup_f32(_p(pl["col_uid"]), _p(pl["col_nu"]), self.B, F, _p(emb), emb.stride(0),
+                                                 self.V, _p(me), _p(ve), me.stride(0), _p(mw), _p(vw), mw.stride(0),
+                                                 _p(self._last), _p(self._step_dev), _p(self._lr_tab),
+                                                 self._lr_tab.numel(), 0.9, 0.999, 1e-7, st),
+                  "rec_adam_keras_catchup_f32")
         if not self.direct:
             check(lib.rec_deepfm_fused_main_f32(
                 _p(emb), emb.stride(0), self.V, arr, F, self.B, _p(L.bias), _p(L.MLP_layer1.kernel_0),
@@ -412,8 +422,10 @@ class DeepFMFusedStep:
             _p(pl["dloc"]), _p(pl["col_nu"]), _p(self.g_embed_rows), st), "rec_deepfm_fused_main_direct_f32")
 
     def _fused_lazy(self):
-        """optimizer 'lazy_adam' in direct mode: the touched-rows Adam of both tables rides in the post launch"""
-        return self.optimizer == "lazy_adam" and self.direct
+        """optimizer 'lazy_adam' / 'keras_adam_lazy' in direct mode: the touched-rows update of both tables rides in the
+        post launch ('keras_adam_lazy': and the rows a batch is about to read first replay the dense sweeps they
+        skipped -- Keras' Adam, bit for bit, without sweeping the table every step; flush() before reading parameters)"""
+        return self.optimizer in ("lazy_adam", "keras_adam_lazy") and self.direct
 
     def _launch_post(self, buf, st, t=0):
         """reduction of the workgroup partials side by side with the segment sums (direct mode: with what is left of
@@ -431,7 +443,8 @@ class DeepFMFusedStep:
                 _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(self.loss), _p(self.ws), _p(pl["perm"]),
                 _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.uniq_ids), _p(self.g_embed_rows),
                 _p(self.g_w_rows), _p(self.n_uniq), _p(pe), pe.stride(0), self.V, _p(me), _p(ve), _p(mw), _p(vw),
-                me.stride(0), mw.stride(0), _p(self._lr_t_dev), 0.9, 0.999, 1e-7, st),
+                me.stride(0), mw.stride(0), _p(self._lr_t_dev), 0.9, 0.999, 1e-7,
+                _p(self._last) if self._last is not None else None, _p(self._step_dev), st),
                 "rec_deepfm_fused_post_direct_adam_dev_f32")
             return
         if not self.direct:
@@ -617,6 +630,18 @@ class DeepFMFusedStep:
         self._prefetched = dict(zip(then_keys, then_bufs))
         self._half = 1 - cur_half if then_cols else cur_half
         return self.loss
+
+    def flush(self):
+        """optimizer 'keras_adam_lazy': bring EVERY row of the tables up to the current step (the dense sweeps the rows
+        skipped) -- before the parameters are read from outside the step (evaluation, checkpoint)."""
+        if not (self._fused_lazy() and self._last is not None):
+            return
+        emb = self.layer.embed.embeddings
+        (me, ve), (mw, vw) = self.state["embed.embeddings"], self.state["w.embeddings"]
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.rec_adam_keras_flush_f32(_p(emb), emb.stride(0), self.V, _p(me), _p(ve), me.stride(0), _p(mw), _p(vw),
+                                           mw.stride(0), _p(self._last), _p(self._step_dev), _p(self._lr_tab),
+                                           self._lr_tab.numel(), 0.9, 0.999, 1e-7, st), "rec_adam_keras_flush_f32")
 
     def check_flags(self):
         if int(self.oob.item()) != 0:

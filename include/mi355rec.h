@@ -354,7 +354,22 @@ int rec_deepfm_fused_post_direct_adam_dev_f32(int F, int64_t B, const float* gz,
                                               float* g_embed_rows, float* g_w_rows, int64_t* n_uniq, float* table,
                                               int64_t ld, int64_t V, float* m_e, float* v_e, float* m_w, float* v_w,
                                               int64_t ld_state, int64_t ld_wstate, const float* lr_t_dev, float b1,
-                                              float b2, float eps, void* stream);
+                                              float b2, float eps, int32_t* last, const int64_t* step_dev, void* stream);
+/* Keras Adam evaluated lazily and exactly (2.FM/ModelManager.py:178-179: the sparse apply of IndexedSlices gradients is
+ * a dense sweep over every row).  An untouched row's update at step j depends only on the row and lr_j, so rows may skip
+ * the sweeps and replay them later with the sweep's own arithmetic: last [V] int32 = the step each row holds (zero at
+ * the start).  rec_adam_keras_catchup_f32 brings the unique rows of a batch's plan (col_uid / col_nu of
+ * rec_colsort_plan_dest_i64) up to step *step_dev BEFORE the batch reads them; the post launch above, given `last`,
+ * applies the touched update of the step that follows and stamps the rows; rec_adam_keras_flush_f32 brings every row up
+ * to date (before the parameters are read from outside).  Rounding is pinned in every Adam kernel of this library, so
+ * the tables equal those of rec_adam_sparse_keras_pair_f32 bit for bit.  lr_table: rec_adam_lr_t_f32 of steps 1..n. */
+int rec_adam_keras_catchup_f32(const int64_t* col_uid, const int32_t* col_nu, int64_t B, int F, float* table, int64_t ld,
+                               int64_t V, float* m_e, float* v_e, int64_t ld_state, float* m_w, float* v_w,
+                               int64_t ld_wstate, const int32_t* last, const int64_t* step_dev, const float* lr_table,
+                               int64_t n_table, float b1, float b2, float eps, void* stream);
+int rec_adam_keras_flush_f32(float* table, int64_t ld, int64_t V, float* m_e, float* v_e, int64_t ld_state, float* m_w,
+                             float* v_w, int64_t ld_wstate, int32_t* last, const int64_t* step_dev, const float* lr_table,
+                             int64_t n_table, float b1, float b2, float eps, void* stream);
 /* segment sums of vals [B*F,16] (embed) and gz [B] (w) over that plan + compaction to the global ascending list:
  * uniq_ids [B*F], g_embed_rows [B*F,16], g_w_rows [B*F], n_uniq; the tail is padded like rec_dedup_plan_i64's. */
 int rec_colseg_sum_f32(const float* vals, const float* gz, const int32_t* perm, const int64_t* col_uid,

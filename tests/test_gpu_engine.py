@@ -371,6 +371,41 @@ def test_fused_step_lazy_adam_in_post_launch(dist):
     assert (a.state["w.embeddings"][1] - b.state["w.embeddings"][1]).abs().max().item() <= 1e-6
 
 
+@pytest.mark.parametrize("dist,use_graph", [("uniform", False), ("zipf", False), ("zipf", True)])
+def test_keras_adam_evaluated_lazily_equals_the_dense_sweep_bit_for_bit(dist, use_graph):
+    """Keras' sparse apply sweeps EVERY row every step (2.FM/ModelManager.py:178-179).  'keras_adam_lazy' lets rows skip
+    the sweeps and replays them -- with the sweep's own arithmetic -- when a batch is about to read the rows (or at
+    flush()): after 9 steps over 5 different batches (rows touched once, repeatedly, with gaps, never) the tables, both
+    moment arrays and the dense parameters must equal those of the dense-sweep implementation bit for bit; and a row the
+    lazy path has NOT brought up to date must differ from it before flush() (the test would be vacuous otherwise)."""
+    from explicit_tf2_recommendation_amd import engine, data
+    B, F, V = 512, 6, 6000
+    la, names, gen = make16(B, F, V, 41, dist)
+    lb, _, _ = make16(B, F, V, 41, dist)
+    lb.load_state_dict(la.state_dict())
+    a = engine.DeepFMFusedStep(la, B, gen.dims, gen.offsets, optimizer="keras_adam", lr=0.01, use_graph=False)
+    b = engine.DeepFMFusedStep(lb, B, gen.dims, gen.offsets, optimizer="keras_adam_lazy", lr=0.01, use_graph=use_graph)
+    batches = [data.to_device(gen.batch(B)) for _ in range(5)]
+    order = [0, 1, 2, 0, 3, 3, 4, 1, 0]
+    for i in order:
+        la_loss = a(batches[i]).item()
+        lb_loss = b(batches[i]).item()
+        assert la_loss == lb_loss, i
+    ea, eb = la.embed.embeddings.detach(), lb.embed.embeddings.detach()
+    stale = (b._last.cpu().numpy() < len(order)) & (b._last.cpu().numpy() > 0)
+    assert stale.any() and not torch.equal(ea, eb)           # some touched rows are behind the sweep
+    b.flush()
+    assert int(b._last.min().item()) == len(order)
+    assert torch.equal(ea, eb) and torch.equal(la.w.embeddings.detach(), lb.w.embeddings.detach())
+    for k in ("embed.embeddings", "w.embeddings"):
+        assert torch.equal(a.state[k][0], b.state[k][0].contiguous()), k
+        assert torch.equal(a.state[k][1], b.state[k][1].contiguous()), k
+    for (k, p), (_, q) in zip(la.named_parameters(), lb.named_parameters()):
+        assert torch.equal(p, q), k
+    # and the steps go on from the flushed state
+    assert a(batches[2]).item() == b(batches[2]).item()
+
+
 def test_fused_lazy_adam_train_steps_replayed_from_graphs_equal_eager_ones():
     """The whole train step with the lazy Adam inside the post launch holds no per-step host scalar (the step counter and
     the bias-corrected step size live on the device), so cycles of steps are captured and replayed: parameters and
