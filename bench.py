@@ -455,6 +455,32 @@ def main():
             lazy_run(nl)
             torch.cuda.synchronize()
             extra["train_step_lazy_adam_ms"] = (time.perf_counter() - t1) / nl * 1e3
+            # Keras Adam itself, evaluated lazily and exactly: rows skip the dense sweeps and replay them right before a
+            # batch reads them (bit-identical tables, tests/test_gpu_engine.py).  What the replay costs depends on how long
+            # rows stay untouched, so this runs on 64 resident batches (a row recurs after up to 64 steps; with fresh
+            # uniform batches the mean gap at 213k of 10M rows per step is ~47) and is timed in the steady state, after
+            # 256 steps; flush_ms = bringing every row up to date afterwards (the sweep that was saved, once).
+            st4 = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, optimizer="keras_adam_lazy", lr=1e-3,
+                                         use_graph=not args.no_graph)
+            fresh = [data.to_device(gen.batch(B)) for _ in range(64)]
+            c4 = 4
+
+            def exact_run():
+                for i in range(0, 64, c4):
+                    st4.many(fresh[i:i + c4], then=fresh[(i + c4) % 64:(i + c4) % 64 + c4])
+
+            for _ in range(4):
+                exact_run()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            exact_run()
+            torch.cuda.synchronize()
+            extra["train_step_keras_adam_lazy_exact_ms"] = (time.perf_counter() - t1) / 64 * 1e3
+            t1 = time.perf_counter()
+            st4.flush()
+            torch.cuda.synchronize()
+            extra["keras_adam_lazy_exact_flush_ms"] = (time.perf_counter() - t1) * 1e3
+            del fresh
 
     if rank == 0:
         out = {"metric": "examples/sec fwd+bwd, DeepFM 10M-vocab x16d batch 8192", "value": value,
