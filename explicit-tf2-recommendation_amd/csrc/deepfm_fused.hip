@@ -1090,35 +1090,69 @@ __global__ __launch_bounds__(1024) void deepfm_post_kernel(ReduceArgs r, ColSegA
 // step the row holds, and before a batch reads its rows this kernel applies the steps last+1 .. *step_dev they missed,
 // element by element with the sweep's own arithmetic (adam_decay) -- the same bits the sweep would have left.  The rows
 // of a batch then receive the touched update of the current step in the post launch, which also sets last.
-// Threads: 16 per unique id of the batch's plan (one embed element each), then one per id for the w element.
 struct CatchArgs {
   const int64_t* col_uid; const int32_t* col_nu; int64_t B; int F;   // plan of the batch; null col_uid: all rows [0, V)
   float* table; int64_t V; float* m_e; float* v_e; int64_t ldm; float* m_w; float* v_w; int64_t ldw;
   const int32_t* last; const int64_t* step_dev; const float* lr_tab; int64_t n_tab; float b1, b2, eps;
 };
-__global__ __launch_bounds__(256) void adam_keras_catchup_kernel(CatchArgs a) {
+// A workgroup takes CATCH_R consecutive slots (unique ids of the plan, or table rows for the flush), looks up how many
+// steps each of them has to replay and hands the rows to its waves in DESCENDING order of that count: a wave of 4 rows x
+// 16 elements runs as long as its longest row, and with the pending counts of a batch spread geometrically (mean ~47 at
+// 213k of 10M rows per step) unsorted waves ran twice the mean.  The first-order weights of the 64 rows follow on the
+// first wave, one lane per row, in the same order.
+constexpr int CATCH_R = 64;
+__global__ __launch_bounds__(CATCH_R * E16) void adam_keras_catchup_kernel(CatchArgs a) {
+  __shared__ int64_t id_s[CATCH_R];
+  __shared__ int j0_s[CATCH_R], k_s[CATCH_R];
+  __shared__ unsigned char ord[CATCH_R];
+  const int tid = threadIdx.x;
   const int64_t nslot = a.col_uid ? a.B * a.F : a.V;
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool is_w = t >= nslot * E16;
-  const int64_t slot = is_w ? t - nslot * E16 : t >> 4;
-  if (slot >= nslot) return;
-  int64_t id = slot;
-  if (a.col_uid) {
-    const int f = (int)(slot / a.B);
-    const int64_t u = slot - (int64_t)f * a.B;
-    if (u >= a.col_nu[f]) return;
-    id = a.col_uid[(int64_t)f * a.B + u];
-    if ((uint64_t)id >= (uint64_t)a.V) return;
+  const int64_t j1 = *a.step_dev;
+  if (tid < CATCH_R) {
+    const int64_t slot = (int64_t)blockIdx.x * CATCH_R + tid;
+    int64_t id = -1;
+    if (slot < nslot) {
+      if (a.col_uid) {
+        const int f = (int)(slot / a.B);
+        const int64_t u = slot - (int64_t)f * a.B;
+        if (u < a.col_nu[f]) id = a.col_uid[(int64_t)f * a.B + u];
+      } else {
+        id = slot;
+      }
+    }
+    int j0 = 0, k = 0;
+    if ((uint64_t)id < (uint64_t)a.V) {
+      j0 = a.last[id];
+      k = j1 > j0 ? (int)(j1 - j0) : 0;
+    }
+    id_s[tid] = id; j0_s[tid] = j0; k_s[tid] = k;
   }
-  const int64_t j0 = a.last[id], j1 = *a.step_dev;
-  if (j0 >= j1) return;
-  float* px = is_w ? a.table + id * LD + E16 : a.table + id * LD + (t & 15);
-  float* pm = is_w ? a.m_w + id * a.ldw : a.m_e + id * a.ldm + (t & 15);
-  float* pv = is_w ? a.v_w + id * a.ldw : a.v_e + id * a.ldm + (t & 15);
-  float x = *px, m = *pm, v = *pv;
-  if (m == 0.f && v == 0.f) return;                    // x - lr*0/(0+eps) = x: a row that was never touched stays put
-  for (int64_t j = j0 + 1; j <= j1; ++j) adam_decay(x, m, v, a.lr_tab[(j < a.n_tab ? j : a.n_tab) - 1], a.b1, a.b2, a.eps);
-  *px = x; *pm = m; *pv = v;
+  __syncthreads();
+  if (tid < CATCH_R) {
+    const int k = k_s[tid];
+    int rank = 0;
+#pragma unroll 8
+    for (int q = 0; q < CATCH_R; ++q) rank += (k_s[q] > k || (k_s[q] == k && q < tid)) ? 1 : 0;
+    ord[rank] = (unsigned char)tid;
+  }
+  __syncthreads();
+  for (int part = 0; part < 2; ++part) {                 // 0: the 16 embedding elements of every row, 1: its w element
+    if (part == 1 && tid >= CATCH_R) break;
+    const int r = part == 0 ? ord[tid >> 4] : ord[tid];
+    const int k = k_s[r];
+    if (k <= 0) continue;
+    const int64_t id = id_s[r];
+    const int e = tid & 15;
+    float* px = part == 0 ? a.table + id * LD + e : a.table + id * LD + E16;
+    float* pm = part == 0 ? a.m_e + id * a.ldm + e : a.m_w + id * a.ldw;
+    float* pv = part == 0 ? a.v_e + id * a.ldm + e : a.v_w + id * a.ldw;
+    float x = *px, m = *pm, v = *pv;
+    if (m == 0.f && v == 0.f) continue;                  // x - lr*0/(0+eps) = x: a row that was never touched stays put
+    const int64_t j0 = j0_s[r];
+    for (int64_t j = j0 + 1; j <= j1; ++j)
+      adam_decay(x, m, v, a.lr_tab[(j < a.n_tab ? j : a.n_tab) - 1], a.b1, a.b2, a.eps);
+    *px = x; *pm = m; *pv = v;
+  }
 }
 __global__ __launch_bounds__(256) void fill_last_kernel(int32_t* __restrict__ last, int64_t V,
                                                         const int64_t* __restrict__ step_dev) {
@@ -1419,7 +1453,7 @@ extern "C" int rec_adam_keras_catchup_f32(const int64_t* col_uid, const int32_t*
   if (rc != REC_OK) return rc;
   CatchArgs a{col_uid, col_nu, B, F, table, V, m_e, v_e, ld_state, m_w, v_w, ld_wstate, last, step_dev, lr_table, n_table,
               b1, b2, eps};
-  hipLaunchKernelGGL(adam_keras_catchup_kernel, dim3((unsigned)ceil_div64(B * F * (E16 + 1), 256)), dim3(256), 0,
+  hipLaunchKernelGGL(adam_keras_catchup_kernel, dim3((unsigned)ceil_div64(B * F, CATCH_R)), dim3(CATCH_R * E16), 0,
                      as_stream(stream), a);
   REC_LAUNCH_CHECK();
   return REC_OK;
@@ -1434,7 +1468,7 @@ extern "C" int rec_adam_keras_flush_f32(float* table, int64_t ld, int64_t V, flo
   if (rc != REC_OK) return rc;
   CatchArgs a{nullptr, nullptr, 0, 0, table, V, m_e, v_e, ld_state, m_w, v_w, ld_wstate, last, step_dev, lr_table,
               n_table, b1, b2, eps};
-  hipLaunchKernelGGL(adam_keras_catchup_kernel, dim3((unsigned)ceil_div64(V * (E16 + 1), 256)), dim3(256), 0,
+  hipLaunchKernelGGL(adam_keras_catchup_kernel, dim3((unsigned)ceil_div64(V, CATCH_R)), dim3(CATCH_R * E16), 0,
                      as_stream(stream), a);
   REC_LAUNCH_CHECK();
   hipLaunchKernelGGL(fill_last_kernel, dim3((unsigned)ceil_div64(V, 256)), dim3(256), 0, as_stream(stream), last, V,
