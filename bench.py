@@ -46,6 +46,9 @@ def parse():
                     help="steps per captured hipGraph (<= 8; must divide --resident); default: 8 when it divides "
                          "--steps (fewer graph launches), else 4")
     ap.add_argument("--step-graphs", action="store_true", help="one hipGraph per step instead of one per 4-step cycle")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: REHEARSAL of the multi-rank control flow on a box with fewer GPUs than ranks -- every rank "
+                         "uses GPU (local_rank mod device count), exchanges hop through host memory (not a measurement)")
     ap.add_argument("--sharded-graph", action="store_true",
                     help="row-sharded step: capture each cycle of steps, RCCL collectives included, in one hipGraph "
                          "(verified at world size 1 only; the default issues the sharded step eagerly)")
@@ -158,13 +161,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    rehearsal = args.dist_backend == "gloo"
+    if rehearsal:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     if world > 1:
         import datetime
         # a collective that never completes surfaces as an error after 5 minutes instead of the 10-minute default
-        dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=5),
-                                device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=5))
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=5),
+                                    device_id=torch.device("cuda", local_rank))
+
+    def reduce_max(x):
+        """max over ranks of a host scalar (the slowest rank's time is the job's time)"""
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
     from explicit_tf2_recommendation_amd import layers, engine, data, ops
 
     V, F, E, B = args.vocab, CFG["fields"], CFG["embedding_dims"], args.batch
@@ -184,7 +199,11 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-        step = engine.ShardedDeepFMStep(layer, B, gen.dims, gen.offsets)
+        if rehearsal:
+            from explicit_tf2_recommendation_amd import sharded as _sh
+            step = engine.ShardedDeepFMStep(layer, B, gen.dims, gen.offsets, comm=_sh.HostStagedComm(None, True))
+        else:
+            step = engine.ShardedDeepFMStep(layer, B, gen.dims, gen.offsets)
     elif args.generic:
         step = engine.DeepFMTrainStep(layer, B, optimizer=None, use_graph=not args.no_graph)
     else:   # per step: fused fwd+bwd kernel, reduction + segment sums (one launch), per-column sort on a second stream
@@ -257,9 +276,7 @@ def main():
     elapsed = time.perf_counter() - t0
     gc.enable()
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = reduce_max(elapsed)
     try:
         step.check_flags() if hasattr(step, "check_flags") else None
         if int(step.oob.item()) != 0:
@@ -296,9 +313,7 @@ def main():
         gc.enable()
         rel = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([rel], device="cuda", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            rel = float(t.item())
+            rel = reduce_max(rel)
         replicas = {"value": world * B * args.steps / rel, "unit": "examples/s", "ms_per_step": rel / args.steps * 1e3,
                     "note": "independent full-table replicas, no exchange (upper bound; not the reported value)"}
 
@@ -509,6 +524,9 @@ def main():
                           "plan of batch k+1 (per-column sort, second stream) overlaps step k"},
                "roofline": roofline, "roofline_gather": roofline_gather, "roofline_gather_e32": roofline_gather_e32,
                "roofline_gather_e64": roofline_gather_e64, "loss": loss}
+        if rehearsal:
+            out["config"]["rehearsal"] = ("--dist-backend gloo: %d ranks share the visible GPUs, exchanges hop through host "
+                                          "memory -- a rehearsal of the multi-rank control flow, NOT a measurement" % world)
         if replicas is not None:
             out["replicas_no_exchange"] = replicas
         out.update(extra)

@@ -86,6 +86,31 @@ class DistComm:
         return x
 
 
+class HostStagedComm(DistComm):
+    """REHEARSAL ONLY: the collectives of a gloo process group with every payload hopping through host memory, for
+    several ranks that share ONE GPU (RCCL refuses two ranks on one device).  Every kernel of the step is the product
+    path; only the exchanges differ.  Used by tests/test_sharded.py and by `bench.py --dist-backend gloo`, which rehearses
+    the multi-rank control flow of the benchmark on a single-GPU box."""
+
+    def exchange(self, x, out):
+        torch.cuda.current_stream().synchronize()
+        h = torch.empty(x.shape, dtype=x.dtype)
+        dist.all_to_all_single(h, x.cpu(), group=self.group)
+        return out.copy_(h)
+
+    def exchange_ids(self, x, out):
+        torch.cuda.current_stream().synchronize()
+        h = torch.empty(x.shape, dtype=x.dtype)
+        dist.all_to_all_single(h, x.cpu(), group=self.count_group)
+        return out.copy_(h)
+
+    def all_reduce_sum(self, x):
+        h = x.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+        x.copy_(h)
+        return x
+
+
 class _Lookup(torch.autograd.Function):
     @staticmethod
     def forward(ctx, local_table, ids, emb):

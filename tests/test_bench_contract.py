@@ -61,3 +61,19 @@ def test_bench_json_line(extra):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-6 and 0.0 < r["frac"] < 1.0
     assert r["traffic"] is None or r["traffic"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """`--gpus 2` started by bench.py itself, the two ranks sharing the one GPU with gloo exchanges through host memory
+    (--dist-backend gloo): the multi-rank control flow of the benchmark -- launcher, rendezvous, row-sharded step with
+    HIP kernels, barriers, max-over-ranks timing, the replicas reference point, rank 0's JSON line relayed by the
+    parent -- runs end to end before a multi-GPU node ever sees it."""
+    rc, out, err = _run(["--gpus", "2", "--dist-backend", "gloo", "--steps", "8", "--warmup", "2", "--no-cpu-baseline",
+                         "--adam-steps", "0"], timeout=900)
+    assert rc == 0, err[-2000:]
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * 8192 and "rehearsal" in d["config"]
+    assert d["value"] > 0 and "replicas_no_exchange" in d and d["scaling"] == "weak"

@@ -352,23 +352,7 @@ def _gpu_step_worker(rank, world, port, V, B, F, result):
     try:
         from explicit_tf2_recommendation_amd import engine, data, layers, sharded
 
-        class HostStagedComm(sharded.DistComm):
-            """gloo between two processes that share the ONE GPU of the test box (RCCL refuses two ranks on one
-            device): payloads hop through host memory, everything else -- every kernel -- is the product path."""
-
-            def exchange(self, x, out):
-                torch.cuda.current_stream().synchronize()
-                h = torch.empty(x.shape, dtype=x.dtype)
-                return out.copy_(super().exchange(x.cpu(), h))
-
-            def exchange_ids(self, x, out):
-                torch.cuda.current_stream().synchronize()
-                h = torch.empty(x.shape, dtype=x.dtype)
-                return out.copy_(super().exchange_ids(x.cpu(), h))
-
-            def all_reduce_sum(self, x):
-                x.copy_(super().all_reduce_sum(x.cpu()))
-                return x
+        HostStagedComm = sharded.HostStagedComm
 
         torch.cuda.set_device(0)
         names = ["f%d" % i for i in range(F)]
