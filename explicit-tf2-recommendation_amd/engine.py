@@ -337,6 +337,9 @@ class DeepFMFusedStep:
         self.col_lo_rep = self.col_lo.repeat(self.GROUP).contiguous()
         self._prefetched, self._half = {}, 0     # plans announced by the previous call: id-tensor addresses -> buffer
         self._col_cache = {}
+        import operator
+        names_ = list(layer.feature_names)
+        self._getter = (operator.itemgetter(*names_) if len(names_) > 1 else (lambda d, n=names_[0]: (d[n],)))
         self.uniq_ids = torch.empty(n, dtype=torch.int64, device=dev)
         self.g_embed_rows = torch.empty((n, 16), **f32)
         self.g_w_rows = torch.empty((n, 1), **f32)
@@ -522,20 +525,17 @@ class DeepFMFusedStep:
     def _cols_key(self, inputs):
         """(columns, their addresses) of a batch.  The 26 dtype / device / size / stride checks and address reads of a
         batch were half of the host time of a call (which the GPU waits for whenever a call starts from an empty
-        queue): done once per batch dict, and again only when a tensor of the dict was replaced."""
+        queue): done once per batch dict, and again only when a tensor of the dict was replaced (identity of the 26
+        tensor objects, compared in C: itemgetter + map(id))."""
         ent = self._col_cache.get(id(inputs))
-        if ent is not None and ent[2] is inputs:
-            cols = ent[0]
-            for name, c in zip(self.layer.feature_names, cols):
-                if inputs[name] is not c:
-                    break
-            else:
-                return cols, ent[1]
+        if ent is not None and ent[2] is inputs and tuple(map(id, self._getter(inputs))) == ent[3]:
+            return ent[0], ent[1]
         cols = self._cols(inputs)
         if len(self._col_cache) > 256:
             self._col_cache.clear()
-        self._col_cache[id(inputs)] = (cols, self._key(cols), inputs)
-        return cols, self._col_cache[id(inputs)][1]
+        key = self._key(cols)
+        self._col_cache[id(inputs)] = (cols, key, inputs, tuple(map(id, cols)))
+        return cols, key
 
     def many(self, batches, label_name="label", then=None):
         """len(batches) consecutive train_loop iterations; with ``use_graph`` as ONE hipGraph replay (a launch-bound
