@@ -85,6 +85,9 @@ SIGNATURES = {
     "rec_colsort_plan_dest_i64": (i32, [p, i32, i64, i64, p, i64, p, p, p, p, p, p, p, p]),
     "rec_deepfm_fused_main_direct_f32": (i32, [p, i64, i64, p, i32, i64] + [p] * 13 + [p, p, p] + [p]),
     "rec_deepfm_fused_post_direct_f32": (i32, [i32, i64] + [p] * 19 + [p]),
+    "rec_deepfm_k0t_f32": (i32, [p, i32, p, p]),
+    "rec_deepfm_fused3_main_f32": (i32, [p, i64, i64, p, i32, i64] + [p] * 14 + [p]),
+    "rec_deepfm_fused3_main_direct_f32": (i32, [p, i64, i64, p, i32, i64] + [p] * 14 + [p, p, p] + [p]),
     "rec_deepfm_fused_post_direct_adam_f32": (i32, [i32, i64] + [p] * 19 + [p, i64, i64, p, p, p, p, i64, f32, f32, f32,
                                                                           f32, p]),
     "rec_colseg_sum_f32": (i32, [p, p, p, p, p, p, i64, i32, p, p, p, p, p]),

@@ -281,9 +281,10 @@ class DeepFMFusedStep:
     """
 
     NBUF = 16           # plan buffers (see __init__): two halves of 8, many() alternates between them
+    MAX_GRAPHS = 64     # captured hipGraphs kept (least recently used beyond that are dropped with the inputs they hold)
 
     def __init__(self, layer, batch_size, field_dims, field_offsets, optimizer=None, lr=1e-3, use_graph=True,
-                 direct=True):
+                 direct=True, kernel=None):
         self.layer = layer
         self.direct = bool(direct)
         self.B = B = int(batch_size)
@@ -303,6 +304,12 @@ class DeepFMFusedStep:
             raise NotImplementedError("field too wide for the 32-bit sort words at this batch size")
         dev = emb.device
         self.dev = dev
+        if optimizer not in (None, "keras_adam", "lazy_adam", "keras_adam_lazy"):
+            raise ValueError("optimizer must be None, 'keras_adam', 'lazy_adam' or 'keras_adam_lazy', not %r" % (optimizer,))
+        if optimizer == "keras_adam_lazy" and not self.direct:
+            # ('lazy_adam' has a plan-after form: rec_adam_rows_f32 over the finished row sums -- the same touched-rows
+            # arithmetic; the lazily EVALUATED Keras Adam only exists inside the direct-mode post launch)
+            raise ValueError("optimizer 'keras_adam_lazy' applies its update inside the direct-mode post launch: direct=True")
         self.optimizer, self.lr, self.use_graph, self.t = optimizer, lr, use_graph, 0
         f32 = dict(dtype=torch.float32, device=dev)
         n, D = B * F, F * 16
@@ -357,6 +364,16 @@ class DeepFMFusedStep:
             # five or six (table row, m_e, v_e, m_w, v_w).  state[...] stays a pair of (strided) views
             fused = getattr(layer, "_fused_storage", None)
             if fused is not None and fused.shape[1] == 32:
+                # floats 17 / 18 of every fused table row are RESERVED for this step's m_w / v_w: the storage must still be
+                # what embed.embeddings views, and only one step may own it (a second one would wipe the first one's state)
+                if fused.data_ptr() != emb.data_ptr():
+                    raise ValueError("layer._fused_storage no longer aliases embed.embeddings")
+                owner = getattr(layer, "_fused_state_owner", None)
+                if owner is not None and owner() is not None and owner() is not self:
+                    raise ValueError("another DeepFMFusedStep already keeps its optimizer state in this layer's table "
+                                     "padding (floats 17/18 of the fused rows): one lazy-optimizer step per layer")
+                import weakref
+                layer._fused_state_owner = weakref.ref(self)
                 self._mv = torch.zeros((self.V, 32), **f32)
                 fused[:, 17:19].zero_()
                 self.state["embed.embeddings"] = (self._mv[:, :16], self._mv[:, 16:])
@@ -379,7 +396,32 @@ class DeepFMFusedStep:
                            (C.c_void_p * k)(*[self.state[nm][1].data_ptr() for nm in names]),
                            (C.c_void_p * k)(*[self.g[nm].data_ptr() for nm in names]),
                            (C.c_int64 * k)(*[self.g[nm].numel() for nm in names]))
-        self._graphs = {}
+        import collections
+        self._graphs = collections.OrderedDict()            # gkey -> (graph, inputs kept alive), LRU order
+        self._seen = collections.OrderedDict()              # gkeys enqueued eagerly once (addresses only: nothing is held)
+        # transposed copy of layer 1's kernel for the fused kernel (csrc/deepfm_fused3.hip reads its K0 operand as 16-byte
+        # pieces of K0^T); refreshed whenever the parameter changed -- by torch (its version counter) or by this step's
+        # own optimizer launches (which re-transpose in the same stream)
+        self.kernel_version = 3 if kernel is None else int(kernel)
+        self._k0t = torch.empty((32, D), **f32)
+        self._k0_ver = None
+
+    def _ensure_k0t(self, st=None):
+        if self.F <= 26:
+            return                                           # K0 is staged in LDS by the kernel itself: K0T is not read
+        K0 = self.layer.MLP_layer1.kernel_0
+        ver = (K0._version, K0.data_ptr())
+        if ver != self._k0_ver:
+            if st is None:
+                st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            check(lib.rec_deepfm_k0t_f32(_p(K0), self.F, _p(self._k0t), st), "rec_deepfm_k0t_f32")
+            self._k0_ver = ver
+
+    def _retranspose(self, st):
+        """after an in-stream update of the dense parameters through the C ABI (torch's version counter does not see it)"""
+        if self.F <= 26:
+            return
+        check(lib.rec_deepfm_k0t_f32(_p(self.layer.MLP_layer1.kernel_0), self.F, _p(self._k0t), st), "rec_deepfm_k0t_f32")
 
     def _sort(self, cols, buf, stream):
         self._sort_group([cols], buf, stream)
@@ -411,6 +453,21 @@ class DeepFMFusedStep:
                                                  _p(self._last), _p(self._step_dev), _p(self._lr_tab),
                                                  self._lr_tab.numel(), 0.9, 0.999, 1e-7, st),
                   "rec_adam_keras_catchup_f32")
+        if self.kernel_version >= 3:
+            self._ensure_k0t(st)
+            if not self.direct:
+                check(lib.rec_deepfm_fused3_main_f32(
+                    _p(emb), emb.stride(0), self.V, arr, F, self.B, _p(L.bias), _p(L.MLP_layer1.kernel_0), _p(self._k0t),
+                    _p(L.MLP_layer1.bias_0), _p(L.MLP_layer1.kernel_1), _p(L.MLP_layer1.bias_1),
+                    _p(L.MLP_layer2.kernel_0), _p(L.MLP_layer2.bias_0), _p(label), _p(self.gz), _p(self.vals), None,
+                    _p(self.oob), _p(self.ws), st), "rec_deepfm_fused3_main_f32")
+                return
+            check(lib.rec_deepfm_fused3_main_direct_f32(
+                _p(emb), emb.stride(0), self.V, arr, F, self.B, _p(L.bias), _p(L.MLP_layer1.kernel_0), _p(self._k0t),
+                _p(L.MLP_layer1.bias_0), _p(L.MLP_layer1.kernel_1), _p(L.MLP_layer1.bias_1), _p(L.MLP_layer2.kernel_0),
+                _p(L.MLP_layer2.bias_0), _p(label), _p(self.gz), _p(self.vals), None, _p(self.oob), _p(self.ws),
+                _p(pl["dloc"]), _p(pl["col_nu"]), _p(self.g_embed_rows), st), "rec_deepfm_fused3_main_direct_f32")
+            return
         if not self.direct:
             check(lib.rec_deepfm_fused_main_f32(
                 _p(emb), emb.stride(0), self.V, arr, F, self.B, _p(L.bias), _p(L.MLP_layer1.kernel_0),
@@ -473,16 +530,16 @@ class DeepFMFusedStep:
             k, var, m, v, g, numel = self._multi
             check(lib.rec_adam_dense_multi_f32(k, var, m, v, g, numel, _p(self._lr_t_dev), b1, b2, eps, st),
                   "rec_adam_dense_multi_f32")
+            self._retranspose(st)
             return
         params = dict(self.layer.named_parameters())
         for name, grad in self.g.items():
             m, v = self.state[name]
             check(lib.rec_adam_dense_f32(_p(params[name]), _p(m), _p(v), _p(grad), grad.numel(), t, lr, b1, b2, eps, st),
                   "rec_adam_dense_f32")
+        self._retranspose(st)
         n = self.B * self.F
         pe, pw = params["embed.embeddings"], params["w.embeddings"]
-        if self._fused_lazy():
-            return                                               # the tables were updated inside the post launch
         if self.optimizer == "keras_adam" and _tables_share_rows(pe, pw):
             # one sweep over the fused [embed | w | pad] rows instead of one per table
             (me, ve), (mw, vw) = self.state["embed.embeddings"], self.state["w.embeddings"]
@@ -610,22 +667,36 @@ class DeepFMFusedStep:
                 main.wait_stream(side)                           # join: the next call relies on the other half
 
         t_base = self.t
+        if self.kernel_version >= 3:
+            self._ensure_k0t()                                   # outside any capture: a replayed graph reads K0T
         if not graphed:
             enqueue_all()
         else:
             ent = self._graphs.get(gkey)
-            if ent is None:
-                # first call with these batches: enqueued eagerly -- that IS this call's work (and sets the kernel
-                # attributes) -- and then captured, without running, for the calls to come.  (With an optimizer in the
-                # step a warm-up followed by a replay would apply the update twice.)
+            if ent is not None:
+                self._graphs.move_to_end(gkey)
+                ent[0].replay()
+            elif gkey not in self._seen:
+                # first sighting of these addresses: plain eager enqueue, no device synchronisation, nothing retained.  An
+                # input pipeline that hands over fresh tensors every batch never gets past this branch (its steps run
+                # eagerly, ~0.15 ms of host time each); one that cycles staging buffers is captured on the next round
+                enqueue_all()
+                self._seen[gkey] = True
+                if len(self._seen) > 8 * self.MAX_GRAPHS:
+                    self._seen.popitem(last=False)
+            else:
+                # second sighting: enqueued eagerly -- that IS this call's work -- and then captured, without running, for
+                # the calls to come.  (With an optimizer in the step a warm-up followed by a replay would apply the update
+                # twice.)
                 enqueue_all()
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                     enqueue_all()
-                self._graphs[gkey] = (g, seq, then_cols)         # keep the inputs alive: the graph holds addresses
-            else:
-                ent[0].replay()
+                self._graphs[gkey] = (g, seq, then_cols)         # the inputs stay alive as long as the graph does
+                del self._seen[gkey]
+                while len(self._graphs) > self.MAX_GRAPHS:
+                    self._graphs.popitem(last=False)             # least recently used: graph and retained inputs go
         self.t = t_base + n
         self._prefetched = dict(zip(then_keys, then_bufs))
         self._half = 1 - cur_half if then_cols else cur_half
@@ -642,6 +713,15 @@ class DeepFMFusedStep:
         check(lib.rec_adam_keras_flush_f32(_p(emb), emb.stride(0), self.V, _p(me), _p(ve), me.stride(0), _p(mw), _p(vw),
                                            mw.stride(0), _p(self._last), _p(self._step_dev), _p(self._lr_tab),
                                            self._lr_tab.numel(), 0.9, 0.999, 1e-7, st), "rec_adam_keras_flush_f32")
+
+    def release(self):
+        """Give up the optimizer state kept in the layer's table padding (lazy optimizers) and the captured graphs, so
+        that another step may be built on the same layer."""
+        owner = getattr(self.layer, "_fused_state_owner", None)
+        if owner is not None and owner() is self:
+            self.layer._fused_state_owner = None
+        self._graphs.clear()
+        self._seen.clear()
 
     def check_flags(self):
         if int(self.oob.item()) != 0:
@@ -790,14 +870,21 @@ class HipStepBackend:
         reduction shares its launch with the segment sums)."""
         st_ = self.step
         w = self.__dict__.get("_a_weights")
+        L = st_.layer
         if w is None:                                        # parameters are updated in place: their addresses stay
-            L = st_.layer
-            w = self._a_weights = (_p(L.bias), _p(L.MLP_layer1.kernel_0), _p(L.MLP_layer1.bias_0),
+            self._k0t = torch.empty((32, st_.F * 16), dtype=torch.float32, device=st_.dev)
+            self._k0_ver = None
+            w = self._a_weights = (_p(L.bias), _p(L.MLP_layer1.kernel_0), _p(self._k0t), _p(L.MLP_layer1.bias_0),
                                    _p(L.MLP_layer1.kernel_1), _p(L.MLP_layer1.bias_1), _p(L.MLP_layer2.kernel_0),
                                    _p(L.MLP_layer2.bias_0))
             self._a_tail = (_p(self.gz), _p(self.vals), None, _p(st_.oob), _p(self.ws))
-        check(lib.rec_deepfm_fused_main_f32(_p(rows_local), 20, rows_local.shape[0], pl["uidx_arr"], st_.F, st_.B, *w,
-                                            _p(y), *self._a_tail, self.st), "rec_deepfm_fused_main_f32")
+        K0 = L.MLP_layer1.kernel_0
+        ver = (K0._version, K0.data_ptr())
+        if ver != self._k0_ver and st_.F > 26:               # layer 1's kernel changed: refresh its transposed copy (only
+            check(lib.rec_deepfm_k0t_f32(_p(K0), st_.F, _p(self._k0t), self.st), "rec_deepfm_k0t_f32")   # read when K0 does
+            self._k0_ver = ver                               # not fit in LDS beside the rows)
+        check(lib.rec_deepfm_fused3_main_f32(_p(rows_local), 20, rows_local.shape[0], pl["uidx_arr"], st_.F, st_.B, *w,
+                                             _p(y), *self._a_tail, self.st), "rec_deepfm_fused3_main_f32")
         return self.vals, self.gz
 
     def local_grad(self, pl, vals, gz):
@@ -917,23 +1004,39 @@ class ShardedDeepFMStep:
 
     def _cols(self, inputs):
         cols = []
+        on_gpu = isinstance(self.be, HipStepBackend)          # the kernels take raw device pointers
         for name in self.layer.feature_names:
             c = inputs[name]
-            if c.dtype != torch.int64 or c.numel() != self.B or not c.is_contiguous():
-                raise ValueError("feature %r must be a contiguous int64 tensor with %d ids" % (name, self.B))
+            if c.dtype != torch.int64 or c.numel() != self.B or not c.is_contiguous() or (on_gpu and not c.is_cuda):
+                raise ValueError("feature %r must be a contiguous int64 %stensor with %d ids"
+                                 % (name, "CUDA " if on_gpu else "", self.B))
             cols.append(c)
         return cols
 
+    def _label(self, inputs, label_name):
+        y = inputs[label_name]
+        on_gpu = isinstance(self.be, HipStepBackend)
+        if y.dtype != torch.float32 or y.numel() != self.B or not y.is_contiguous() or (on_gpu and not y.is_cuda):
+            raise ValueError("label must be a contiguous float32 %stensor with %d entries" % ("CUDA " if on_gpu else "", self.B))
+        return y
+
     def _cols_key(self, inputs):
         """(columns, their addresses) of a batch; validated once per batch dict (the host is the bottleneck of the eager
-        step: 26 dtype / size / stride checks per call were a tenth of it)."""
+        step: 26 dtype / size / stride checks per call were a tenth of it) and again whenever a tensor of the dict was
+        replaced (identity of the tensor objects, as in DeepFMFusedStep._cols_key)."""
         cache = self.__dict__.setdefault("_col_cache", {})
+        getter = self.__dict__.get("_getter")
+        if getter is None:
+            import operator
+            names_ = list(self.layer.feature_names)
+            getter = self._getter = (operator.itemgetter(*names_) if len(names_) > 1
+                                     else (lambda d, n=names_[0]: (d[n],)))
         ent = cache.get(id(inputs))
-        if ent is None or ent[2] is not inputs:
+        if ent is None or ent[2] is not inputs or tuple(map(id, getter(inputs))) != ent[3]:
             cols = self._cols(inputs)
             if len(cache) > 256:
                 cache.clear()
-            ent = cache[id(inputs)] = (cols, tuple(c.data_ptr() for c in cols), inputs)
+            ent = cache[id(inputs)] = (cols, tuple(c.data_ptr() for c in cols), inputs, tuple(map(id, cols)))
         return ent[0], ent[1]
 
     def _plan(self, cols, buf, on_side):
@@ -947,7 +1050,7 @@ class ShardedDeepFMStep:
         be, comm = self.be, self.comm
         be.begin()
         cols, key = self._cols_key(inputs)
-        y = inputs[label_name]
+        y = self._label(inputs, label_name)
         if self._next is not None and self._next[0] == key:
             _, buf, pl = self._next
             be.join()                                        # the plan was built on the second stream
@@ -978,7 +1081,8 @@ class ShardedDeepFMStep:
         has constant sizes and nothing is read back, so the sequence is a fixed program).  The plan of the first batch
         is built inside the graph on the main stream, the plans of the following ones on the second stream beside the
         step before.  Every rank must call it with the same number of batches.  Returns the loss of the last step."""
-        key = tuple(self._cols(b)[0].data_ptr() for b in batches) + tuple(b[label_name].data_ptr() for b in batches)
+        key = (tuple(self._cols_key(b)[1] for b in batches) +
+               tuple(self._label(b, label_name).data_ptr() for b in batches))     # every column and label address
         graphs = self.__dict__.setdefault("_graphs", {})
         g = graphs.get(key)
         if g is None:

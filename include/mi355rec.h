@@ -332,6 +332,22 @@ int rec_deepfm_fused_post_direct_f32(int F, int64_t B, const float* gz, const fl
                                      void* workspace, const int32_t* perm, const int64_t* col_uid, const int32_t* col_seg,
                                      const int32_t* col_nu, int64_t* uniq_ids, float* g_embed_rows, float* g_w_rows,
                                      int64_t* n_uniq, void* stream);
+/* Third form of the fused forward+backward kernel (csrc/deepfm_fused3.hip): same inputs, outputs and workspace layout as
+ * rec_deepfm_fused_main_f32 / rec_deepfm_fused_main_direct_f32 -- the post launches above finish the step -- on a schedule
+ * in which the two 16-example halves of a workgroup run one phase apart (the backward of one half on the matrix cores
+ * while the rows of the other are still landing).  K0T [32, F*16] = the transpose of K0 [F*16, 32], kept by the caller
+ * with rec_deepfm_k0t_f32 (layer 1 then reads its K0 operand as 16-byte pieces). */
+int rec_deepfm_k0t_f32(const float* K0, int F, float* K0T, void* stream);
+int rec_deepfm_fused3_main_f32(const float* table, int64_t ld, int64_t V, const int64_t* const* cols_host, int F,
+                               int64_t B, const float* bias, const float* K0, const float* K0T, const float* b0,
+                               const float* K1, const float* b1, const float* K2, const float* b2, const float* label,
+                               float* gz, float* vals, float* prob, int* oob_flag, void* workspace, void* stream);
+int rec_deepfm_fused3_main_direct_f32(const float* table, int64_t ld, int64_t V, const int64_t* const* cols_host, int F,
+                                      int64_t B, const float* bias, const float* K0, const float* K0T, const float* b0,
+                                      const float* K1, const float* b1, const float* K2, const float* b2,
+                                      const float* label, float* gz, float* vals, float* prob, int* oob_flag,
+                                      void* workspace, const int32_t* dloc, const int32_t* col_nu, float* g_embed_rows,
+                                      void* stream);
 /* rec_deepfm_fused_post_direct_f32 + the lazy (touched-rows) Adam update of both tables applied to each row the moment its
  * gradient is final (optimizer in the backward; arithmetic of rec_adam_rows_f32; NOT Keras' dense-sweep
  * semantics of 2.FM/ModelManager.py:104,178-179 -- opt-in).  table: fused rows [V,32] = [embed 16 | w | pad] (ld = 32);

@@ -177,8 +177,10 @@ def test_fused_step_matches_oracle(use_graph, B, F, V, dist):
         batch = gen.batch(B)
         dbatch = data.to_device(batch)
         loss = step(dbatch)
-        if use_graph:
+        if use_graph:                                        # eager, eager + capture, replay
             loss = step(dbatch)
+            loss = step(dbatch)
+            assert len(step._graphs) == it + 1
         step.check_flags()
         ref_loss, ref = oracle_grads(layer, names, batch)
         assert abs(loss.item() - ref_loss) <= 1e-5 * max(1, abs(ref_loss))
@@ -207,7 +209,7 @@ def test_fused_step_pipelined_plan(use_graph):
     devb = [data.to_device(b) for b in host]
     refs = [oracle_grads(layer, names, b) for b in host]
     order = [(0, 1), (1, 2), (2, 0), (0, 1), (1, 2), (0, 2), (2, None), (1, 0)]   # (batch, announced next batch)
-    for cur, nxt in order:
+    for cur, nxt in order * (3 if use_graph else 1):         # graphs: first sighting eager, second captured, then replays
         loss = step(devb[cur], next_inputs=devb[nxt] if nxt is not None else None)
         step.check_flags()
         ref_loss, ref = refs[cur]
@@ -244,8 +246,9 @@ def test_fused_step_multi_step_graph_equals_single_steps():
         return out
 
     # `then` = None, one batch, or the list of batches of the next call (all of their plans are built beside this call)
-    for seq, then in (([0, 1, 2, 3], 0), ([0, 1, 2, 3], 0), ([2, 1], None), ([3], 1), ([1, 0, 2], None),
-                      ([0, 1], [2, 3]), ([2, 3], [0, 1]), ([0, 1], [3, 2, 1]), ([3, 1, 2], [0]), ([0, 0], [0, 0]), ([0, 0], None)):
+    cases = (([0, 1, 2, 3], 0), ([0, 1, 2, 3], 0), ([2, 1], None), ([3], 1), ([1, 0, 2], None),
+             ([0, 1], [2, 3]), ([2, 3], [0, 1]), ([0, 1], [3, 2, 1]), ([3, 1, 2], [0]), ([0, 0], [0, 0]), ([0, 0], None))
+    for seq, then in cases * 3:                              # first sighting eager, second captured, third replayed
         for i in seq:
             one(devb[i])
         want = snapshot(one)
@@ -255,6 +258,48 @@ def test_fused_step_multi_step_graph_equals_single_steps():
         got = snapshot(multi)
         for k in want:
             assert torch.equal(want[k], got[k]), (seq, then, k)
+    assert len(multi._graphs) >= 4                           # the replay path was exercised
+
+
+def test_fused_step_fresh_batches_neither_recapture_nor_grow():
+    """An input pipeline that hands over NEW tensors every batch: with a train step inside the graph (lazy Adam) every
+    unseen set of addresses runs eagerly -- no device synchronisation, no capture, nothing retained -- and the graph
+    cache is a bounded LRU; a pipeline that cycles a ring of staging buffers is captured once per slot and replayed."""
+    from explicit_tf2_recommendation_amd import engine, data
+    B, F, V = 256, 5, 5547
+    layer, names, gen = make16(B, F, V, 31, "zipf")
+    step = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, optimizer="lazy_adam", lr=0.01, use_graph=True)
+    step.MAX_GRAPHS = 4
+    keep = []                                                # keeps every batch alive: all addresses are distinct
+    for i in range(40):
+        b = data.to_device(gen.batch(B))
+        keep.append(b)
+        step(b)
+    assert len(step._graphs) == 0 and len(step._seen) <= 8 * step.MAX_GRAPHS and step.t == 40
+    torch.cuda.synchronize()
+    m0 = torch.cuda.memory_allocated()
+    ring = keep[:8]                                          # a ring of 8 staging buffers, refilled in place
+    fresh = [gen.batch(B) for _ in range(8)]
+    for rnd in range(6):
+        for slot, b in enumerate(ring):
+            src = fresh[(slot + rnd) % 8]
+            for k in b:
+                b[k].copy_(torch.from_numpy(src[k]))
+            step(b)
+        assert len(step._graphs) <= step.MAX_GRAPHS
+    assert len(step._graphs) == step.MAX_GRAPHS              # 8 slots, 4 graphs: the least recently used were dropped
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated() - m0 < (8 << 20)    # nothing accumulates beyond the bounded cache
+    step.check_flags()
+    # one lazy-optimizer step per layer: the table padding holds its state
+    with pytest.raises(ValueError):
+        engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, optimizer="lazy_adam", use_graph=False)
+    step.release()
+    engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, optimizer="lazy_adam", use_graph=False)
+    with pytest.raises(ValueError):
+        engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, optimizer="adamw")
+    with pytest.raises(ValueError):
+        engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, optimizer="keras_adam_lazy", direct=False)
 
 
 def test_fused_step_equals_generic_step_and_is_deterministic():

@@ -341,6 +341,29 @@ def test_sharded_deepfm_step_world1_matches_fused_step():
         assert nu == int(rnu.item()) and torch.equal(ids[:nu], rid[:nu])      # local id = global id at world 1
         assert (rows_e[:nu] - re_[:nu]).abs().max().item() <= 1e-6
         assert (rows_w[:nu] - g_ref["w.embeddings"][1][:nu]).abs().max().item() <= 1e-6
+        # a loader that refills a batch dict with NEW tensors: the cached column list must not be used (the old ids would
+        # be trained on silently); wrong label / column types are refused before any pointer reaches a kernel
+        batch3 = data.to_device(gen.batch(B))
+        for k in names:
+            batch[k] = batch3[k]
+        batch["label"] = batch3["label"]
+        assert abs(sh(batch).item() - ref(batch3).item()) <= 1e-6
+        g_ref3 = ref.gradients()
+        for k, v in sh.g.items():
+            assert torch.equal(v, g_ref3[k]), k
+        for wrong in (batch3["label"].double(), batch3["label"].cpu(), batch3["label"][: B // 2]):
+            with pytest.raises(ValueError):
+                sh(dict(batch3, label=wrong))
+        with pytest.raises(ValueError):
+            sh(dict(batch3, **{names[0]: batch3[names[0]].cpu()}))
+        # many(): the graph key covers every column, so two cycles that differ in one inner column are two graphs
+        other = dict(batch2)
+        other[names[7]] = batch3[names[7]]
+        la = sh.many([batch3, batch2]).item()
+        lb = sh.many([batch3, other]).item()
+        assert len(sh._graphs) == 2
+        assert abs(sh.many([batch3, batch2]).item() - la) == 0 and la != lb
+        sh.release_graphs()
     finally:
         dist.destroy_process_group()
 
