@@ -39,12 +39,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=CFG["batch"])
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly (no hipGraph replay)")
-    ap.add_argument("--resident", type=int, default=16,
-                    help="distinct batches resident in HBM and cycled through (16 x 27 MB of table rows > the 256 MB "
+    ap.add_argument("--resident", type=int, default=32,
+                    help="distinct batches resident in HBM and cycled through (32 x 27 MB of table rows > the 256 MB "
                          "memory-side cache: no step finds its rows cached from the previous cycle)")
     ap.add_argument("--cycle", type=int, default=0,
-                    help="steps per captured hipGraph (<= 8; must divide --resident); default: 8 when it divides "
-                         "--steps (fewer graph launches), else 4")
+                    help="steps per captured hipGraph (<= 32); default: the largest divisor of --steps that is <= 32")
     ap.add_argument("--step-graphs", action="store_true", help="one hipGraph per step instead of one per 4-step cycle")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: REHEARSAL of the multi-rank control flow on a box with fewer GPUs than ranks -- every rank "
@@ -189,11 +188,16 @@ def main():
                                       mlp_dims=CFG["mlp_dims"]).cuda()
     gen = data.SyntheticGenerator(names, V, dist=args.dist, seed=rank)
     n_batches = args.resident
-    Cy = args.cycle or (8 if args.steps % 8 == 0 else 4)
-    if n_batches % Cy or Cy > 8:
-        raise SystemExit("--cycle must divide --resident and be <= 8")
+    # steps per captured hipGraph: the largest divisor of K that a call can hold (32).  A graph launch leaves the GPU idle for
+    # ~30 us (kernel trace: profiles/r03_*), so K = 20 runs as ONE 20-step graph and K = 200 as eight 25-step graphs
+    # (no batch twice in one call: the second occurrence would not find a prefetched plan and be sorted in line)
+    Cy = args.cycle or max(d for d in range(1, min(32, n_batches) + 1) if args.steps % d == 0)
+    if Cy > min(32, n_batches):
+        raise SystemExit("--cycle must be <= min(32, --resident)")
     batches = [data.to_device(gen.batch(B)) for _ in range(n_batches)]
     sharded_mode = args.sharded or (world > 1 and not args.replicas)
+    if sharded_mode and not args.cycle:          # the sharded step's graphs hold a slice of the resident batches
+        Cy = 8 if args.steps % 8 == 0 else 4
     if sharded_mode:    # table rows block-partitioned over the ranks; ids / rows / row gradients by RCCL all-to-all
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -267,8 +271,8 @@ def main():
     # before the opening barrier: (1) no graph is captured inside the timed region whatever K is; (2) the GPU goes into it
     # busy -- after an idle stretch (the 45-ms collection above is one) the first ~150 us of work run at idle clocks,
     # which at K = 20 is a tenth of the region.
-    run_steps(args.steps)
-    run_steps(args.steps)
+    for _ in range(4):       # a graph is captured at the SECOND sighting of a call's addresses, and every call has two
+        run_steps(args.steps)    # forms (the plan-buffer ring has two halves): four rehearsals leave nothing to capture
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps)
@@ -304,8 +308,8 @@ def main():
         rrun(nw)
         gc.collect()
         gc.disable()
-        rrun(args.steps)
-        rrun(args.steps)
+        for _ in range(4):
+            rrun(args.steps)
         barrier()
         t0 = time.perf_counter()
         rrun(args.steps)
@@ -456,15 +460,15 @@ def main():
             # the step counter lives on the device, so whole train steps replay from hipGraphs like the gradient-only ones
             st3 = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, optimizer="lazy_adam", lr=1e-3,
                                          use_graph=not args.no_graph)
-            nl = 4 * max(1, (4 * args.adam_steps + 3) // 4)
+            nl = Cy * max(1, (4 * args.adam_steps + Cy - 1) // Cy)
 
             def lazy_run(n):
                 for cur, nxt in calls_of(n):
                     st3.many(cur, then=nxt)
 
             lazy_run(2 * n_batches)                               # captures the graphs of the resident batches
-            lazy_run(nl)                                          # ... and of the timed sequence itself, twice: the
-            lazy_run(nl)                                          # plan-buffer ring has two halves
+            for _ in range(4):                                    # ... and of the timed sequence itself (captured at the second
+                lazy_run(nl)                                      # sighting, two forms per call: the plan ring has two halves)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             lazy_run(nl)
@@ -475,6 +479,7 @@ def main():
             # rows stay untouched, so this runs on 64 resident batches (a row recurs after up to 64 steps; with fresh
             # uniform batches the mean gap at 213k of 10M rows per step is ~47) and is timed in the steady state, after
             # 256 steps; flush_ms = bringing every row up to date afterwards (the sweep that was saved, once).
+            st3.release()                                         # one lazy-optimizer step per layer (table padding)
             st4 = engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, optimizer="keras_adam_lazy", lr=1e-3,
                                          use_graph=not args.no_graph)
             fresh = [data.to_device(gen.batch(B)) for _ in range(64)]
@@ -484,7 +489,7 @@ def main():
                 for i in range(0, 64, c4):
                     st4.many(fresh[i:i + c4], then=fresh[(i + c4) % 64:(i + c4) % 64 + c4])
 
-            for _ in range(4):
+            for _ in range(6):
                 exact_run()
             torch.cuda.synchronize()
             t1 = time.perf_counter()

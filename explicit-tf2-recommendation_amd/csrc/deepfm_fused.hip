@@ -643,8 +643,22 @@ struct ColSortArgs {
 // ------------------------------------------------------------------------------------------------
 constexpr int OW_T = 1024, OW_W = OW_T / 64, OW_BINS = 128, OW_DB = 7;
 
+#ifdef REC_SORT_STAMPS
+__device__ unsigned long long g_sort_stamps[256 * 16];
+#define SSTAMP(k) do { if (threadIdx.x == 0) g_sort_stamps[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define SSTAMP(k) do {} while (0)
+#endif
+
+// up to 256 columns per launch (8 batches of 26..32 columns: ONE launch per 8 upcoming batches -- every sort launch holds
+// its CUs for the duration of a latency-bound kernel, and a fused kernel that finds CUs taken runs a second round)
+constexpr int SORT_MAX_COLS = 256;
+struct SortCols {
+  const int64_t* p[SORT_MAX_COLS];
+};
+
 template <int KPT>
-__global__ __launch_bounds__(OW_T, KPT <= 8 ? 8 : 4) void colsort_onewg_kernel(Cols cols, const int64_t* __restrict__ col_lo, ColSortArgs a) {
+__global__ __launch_bounds__(OW_T, 4) void colsort_onewg_kernel(SortCols cols, const int64_t* __restrict__ col_lo, ColSortArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t owl[];
   constexpr int NW = OW_T * KPT;                       // padded word count
   uint32_t* words = owl;                               // [NW]
@@ -658,6 +672,7 @@ __global__ __launch_bounds__(OW_T, KPT <= 8 ? 8 : 4) void colsort_onewg_kernel(C
   const int pb = a.pos_bits;
   const uint32_t pmask = (1u << pb) - 1u;
   // ---- load: word = (id - lo) << pos_bits | example; pad words sort last
+  SSTAMP(0);
   bool bad = false;
 #pragma unroll
   for (int r = 0; r < KPT; ++r) {
@@ -675,7 +690,9 @@ __global__ __launch_bounds__(OW_T, KPT <= 8 ? 8 : 4) void colsort_onewg_kernel(C
     words[e] = w;
   }
   if (bad && a.bad) *a.bad = 1;
+  SSTAMP(1);
   const unsigned long long lt = (1ull << lane) - 1ull;
+  int pass_ = 0;
   // ---- radix passes over the key bits
   for (int shift = pb; shift < pb + a.key_bits; shift += OW_DB) {
     reinterpret_cast<uint32_t*>(cnt)[tid] = 0;         // OW_W*OW_BINS/2 = 1024 words
@@ -726,6 +743,8 @@ __global__ __launch_bounds__(OW_T, KPT <= 8 ? 8 : 4) void colsort_onewg_kernel(C
       words[dbase[d] + cnt[wave * OW_BINS + d] + loc[r]] = w[r];
     }
     __syncthreads();
+    SSTAMP(2 + pass_);
+    ++pass_;
   }
   // ---- run heads: thread t owns the KPT consecutive sorted positions from t*KPT
   const int s0 = tid * KPT;
@@ -756,21 +775,67 @@ __global__ __launch_bounds__(OW_T, KPT <= 8 ? 8 : 4) void colsort_onewg_kernel(C
     all += c;
   }
   int rank = woff + incl - heads;
+  // Outputs go through LDS and leave coalesced.  (Stored straight from the registers -- a lane owns 8 consecutive sorted
+  // positions -- every wave instruction wrote 64 scattered 4- or 8-byte pieces: ~32 such instructions per wave on one
+  // address path, and the last wave finished 12 us after the first, 36 us into a kernel whose sort is done at 19.)
+  //   st_uq [rank]    key of the run (aliases `words`: every thread holds its words in registers behind the barrier above)
+  //   st_sg [rank]    first sorted position of the run         (16 bit: B <= 16384)
+  //   st_dl [example] run index | 0x8000 unless head of its run (16 bit)
+  uint32_t* st_uq = words;
+  unsigned short* st_sg = reinterpret_cast<unsigned short*>(wtot + OW_W);
+  unsigned short* st_dl = st_sg + NW;
+  int32_t* permf = a.perm + (int64_t)f * B;
+  if ((B & 7) == 0 && KPT == 8) {
+    // the thread's 8 consecutive perm entries as two 16-byte stores: a wave writes 2 KB of contiguous memory
+    if (s0 < B) {
+      int4 p0 = make_int4((int)(v[0] & pmask), (int)(v[1] & pmask), (int)(v[2] & pmask), (int)(v[3] & pmask));
+      int4 p1 = make_int4((int)(v[4 % KPT] & pmask), (int)(v[5 % KPT] & pmask), (int)(v[6 % KPT] & pmask), (int)(v[7 % KPT] & pmask));
+      *reinterpret_cast<int4*>(permf + s0) = p0;
+      *reinterpret_cast<int4*>(permf + s0 + 4) = p1;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < KPT; ++r)
+      if (s0 + r < B) permf[s0 + r] = (int32_t)(v[r] & pmask);
+  }
 #pragma unroll
   for (int r = 0; r < KPT; ++r) {
     const int sp = s0 + r;
     if (sp < B) {
-      a.perm[(int64_t)f * B + sp] = (int32_t)(v[r] & pmask);
       if (hd[r]) {
-        a.col_uid[(int64_t)f * B + rank] = lo + (int64_t)(v[r] >> pb);
-        a.col_seg[(int64_t)f * (B + 1) + rank] = sp;
+        st_uq[rank] = v[r] >> pb;
+        st_sg[rank] = (unsigned short)sp;
         ++rank;
       }
-      if (a.dloc) a.dloc[(int64_t)f * B + (v[r] & pmask)] = hd[r] ? rank - 1 : (int32_t)((uint32_t)(rank - 1) | 0x80000000u);
-      if (sp + 1 >= all) a.col_seg[(int64_t)f * (B + 1) + sp + 1] = (int32_t)B;     // tail [all .. B] = B
+      st_dl[v[r] & pmask] = (unsigned short)(hd[r] ? (rank - 1) : ((rank - 1) | 0x8000));
     }
   }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < KPT; ++r) {
+    const int i = r * OW_T + tid;
+    if (i < B) {
+      if (a.dloc) {
+        const uint32_t d = st_dl[i];
+        a.dloc[(int64_t)f * B + i] = (int32_t)((d & 0x7FFFu) | ((d & 0x8000u) << 16));
+      }
+      if (i < all) {
+        a.col_uid[(int64_t)f * B + i] = lo + (int64_t)st_uq[i];
+        a.col_seg[(int64_t)f * (B + 1) + i] = (int32_t)st_sg[i];
+      } else {
+        a.col_seg[(int64_t)f * (B + 1) + i] = (int32_t)B;           // tail [all .. B] = B
+      }
+    }
+  }
+  if (tid == 0) a.col_seg[(int64_t)f * (B + 1) + B] = (int32_t)B;
   if (tid == 0) a.col_nu[f] = all;
+  SSTAMP(8);
+#ifdef REC_SORT_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SSTAMP(9);
+  if (threadIdx.x == 1023) g_sort_stamps[blockIdx.x * 16 + 10] = wall_clock64();
+  if (threadIdx.x == 512) g_sort_stamps[blockIdx.x * 16 + 11] = wall_clock64();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1168,6 +1233,11 @@ extern "C" size_t rec_deepfm_fused_workspace_bytes(int64_t B, int F) {
   return sizeof(float) * nwg * ((size_t)F * E16 * U1 + SMALL) + 256;
 }
 
+#ifdef REC_SORT_STAMPS
+extern "C" int rec_debug_sort_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_sort_stamps), sizeof(unsigned long long) * 256 * 16);
+}
+#endif
 #ifdef REC_FUSED_STAMPS
 // diagnostic build only (scripts/exp/fused_stamps.py builds it into its own library): phase stamps of the last launch
 static unsigned long long* g_fused_stamps = nullptr;
@@ -1488,14 +1558,14 @@ static int colsort_plan(const int64_t* const* cols_host, int F, int64_t B, int64
   if (!cols_host || !col_lo || !perm || !col_uid || !col_seg || !col_nu || !workspace || F <= 0 || B <= 0 || V <= 0 ||
       max_key < 0)
     return REC_E_ARG;
-  if (F > REC_MAX_COLS || B > 16384) return REC_E_UNSUPPORTED;
+  if (F > SORT_MAX_COLS || B > 16384) return REC_E_UNSUPPORTED;
   int pos_bits = 1, key_bits = 1;
   while ((int64_t(1) << pos_bits) < B) ++pos_bits;
   while ((int64_t(1) << key_bits) <= max_key) ++key_bits;
   if (key_bits + pos_bits > 32) return REC_E_UNSUPPORTED;
   // the pad word 0xFFFFFFFF must be larger than every real (key, position) word
   if ((((uint64_t)max_key << pos_bits) | (uint64_t)(B - 1)) >= 0xFFFFFFFFull) return REC_E_UNSUPPORTED;
-  Cols cp;
+  SortCols cp;
   for (int f = 0; f < F; ++f) {
     if (!cols_host[f]) return REC_E_ARG;
     cp.p[f] = cols_host[f];
@@ -1506,7 +1576,9 @@ static int colsort_plan(const int64_t* const* cols_host, int F, int64_t B, int64
   // (B <= 16384)
   {
     const int kpt = B <= 8192 ? 8 : 16;
-    const size_t lds = sizeof(uint32_t) * ((size_t)OW_T * kpt + OW_W * OW_BINS / 2 + OW_BINS + OW_W);
+    // words + counters + the 16-bit staging arrays of the outputs (st_sg, st_dl)
+    const size_t lds = sizeof(uint32_t) * ((size_t)OW_T * kpt + OW_W * OW_BINS / 2 + OW_BINS + OW_W) +
+                       2 * sizeof(unsigned short) * (size_t)OW_T * kpt;
     hipError_t e;
     if (kpt == 8) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(colsort_onewg_kernel<8>),

@@ -280,7 +280,8 @@ class DeepFMFusedStep:
     ``self.bad_ids`` (checked by ``check_flags()``).
     """
 
-    NBUF = 16           # plan buffers (see __init__): two halves of 8, many() alternates between them
+    NBUF = 64           # plan buffers (see __init__): two halves of 32, many() alternates between them (a hipGraph launch
+                        # leaves the GPU idle for ~30 us, so a call may hold up to 32 steps: ~1 us per step at that length)
     MAX_GRAPHS = 64     # captured hipGraphs kept (least recently used beyond that are dropped with the inputs they hold)
 
     def __init__(self, layer, batch_size, field_dims, field_offsets, optimizer=None, lr=1e-3, use_graph=True,
@@ -340,7 +341,7 @@ class DeepFMFusedStep:
                            col_nu=self._col_nu[b], dloc=self._dloc[b]) for b in range(NB)]
         # consecutive buffers are contiguous, so ONE sort call can build the plans of GROUP upcoming batches as
         # GROUP*F columns (the sort kernels are latency-bound at < 1 wave per SIMD: two batches cost ~1.2x one)
-        self.GROUP = max(1, min(4, 128 // F))
+        self.GROUP = max(1, min(8, 256 // F))
         self.col_lo_rep = self.col_lo.repeat(self.GROUP).contiguous()
         self._prefetched, self._half = {}, 0     # plans announced by the previous call: id-tensor addresses -> buffer
         self._col_cache = {}
