@@ -349,3 +349,84 @@ extern "C" int rec_colsort_shard_map_fixed_i64(const int32_t* perm, const int64_
   REC_LAUNCH_CHECK();
   return REC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// De-duplicate-first, fixed-capacity exchange map of a GENERIC lookup (any layer: DSSM towers, DCN, DIN's profile +
+// behaviour series): given the sorted-unique plan of the flat id list (rec_dedup_plan_i64: uniq_ids ascending, seg_start,
+// perm, *n_uniq) and the block partition owner = id / rows_per_shard, the ascending unique list is already grouped by
+// owner, so owner o's ids are the slice [first(o), first(o+1)) found by binary search:
+//   msg  [n_shard, 2 + cap] int64   word 0 = ids for this owner, word 1 = 0, then owner-local ids ascending (the layout
+//                                   rec_emb_gather_lists_f32 / rec_dedup_plan_sorted_slabs_i64 read); slots beyond the
+//                                   count keep what the caller put there (zeros)
+//   slot [n] int64                  for lookup i: owner * cap + rank of its id inside the owner's slice = its row in the
+//                                   [n_shard * cap, E] buffer the rows come back in
+// One launch, two independent jobs (no cross-thread dependency): thread j < n_uniq writes unique j's message word,
+// thread p < n finds the unique id of sorted position p (upper bound in seg_start) and writes slot[perm[p]].
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ int64_t lower_bound_i64(const int64_t* a, int64_t n, int64_t key) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void shard_slab_map_kernel(const int64_t* __restrict__ uniq, const int64_t* __restrict__ n_uniq_p,
+                                                             const int32_t* __restrict__ seg_start,
+                                                             const int32_t* __restrict__ perm, int64_t n,
+                                                             int64_t rows_per_shard, int n_shard, int64_t cap,
+                                                             int64_t* __restrict__ msg, int64_t* __restrict__ slot,
+                                                             int* __restrict__ flag) {
+  __shared__ int64_t first_s[MAX_SHARD + 1];
+  const int64_t nu = *n_uniq_p;
+  if (threadIdx.x <= n_shard)                    // first unique index of every owner's slice (and the end)
+    first_s[threadIdx.x] = threadIdx.x == n_shard ? nu : lower_bound_i64(uniq, nu, (int64_t)threadIdx.x * rows_per_shard);
+  __syncthreads();
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < n_shard) {                             // headers
+    const int64_t c = first_s[t + 1] - first_s[t];
+    msg[t * (cap + 2)] = c < cap ? c : cap;
+    msg[t * (cap + 2) + 1] = 0;
+    if (c > cap && flag) *flag = 1;              // more unique ids for one owner than the exchange capacity
+  }
+  if (t < nu) {                                  // message word of unique t
+    const int64_t id = uniq[t];
+    int o = (int)(id / rows_per_shard);
+    if (o < 0 || o >= n_shard) { o = o < 0 ? 0 : n_shard - 1; if (flag) *flag = 1; }
+    const int64_t r = t - first_s[o];
+    if (r < cap) msg[(int64_t)o * (cap + 2) + 2 + r] = id - (int64_t)o * rows_per_shard;
+  }
+  if (t < n) {                                   // slot of the lookup behind sorted position t
+    int64_t lo = 0, hi = nu;                     // largest j with seg_start[j] <= t
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)seg_start[mid] <= t) lo = mid + 1; else hi = mid;
+    }
+    const int64_t j = lo > 0 ? lo - 1 : 0;
+    const int64_t id = uniq[j];
+    int o = (int)(id / rows_per_shard);
+    o = o < 0 ? 0 : (o >= n_shard ? n_shard - 1 : o);
+    int64_t r = j - first_s[o];
+    if (r >= cap) r = cap - 1;                   // overflow was flagged above: stay inside the buffer
+    slot[perm[t]] = (int64_t)o * cap + r;
+  }
+}
+
+}  // namespace
+
+extern "C" int rec_shard_slab_map_i64(const int64_t* uniq_ids, const int64_t* n_uniq, const int32_t* seg_start,
+                                      const int32_t* perm, int64_t n, int64_t rows_per_shard, int n_shard, int64_t cap,
+                                      int64_t* msg, int64_t* slot, int* oob_flag, void* stream) {
+  if (n < 0 || rows_per_shard <= 0 || n_shard <= 0 || cap <= 0) return REC_E_ARG;
+  if (n_shard > MAX_SHARD) return REC_E_UNSUPPORTED;
+  if (n == 0) return REC_OK;
+  if (!uniq_ids || !n_uniq || !seg_start || !perm || !msg || !slot) return REC_E_ARG;
+  const int64_t threads = n > n_shard ? n : n_shard;
+  hipLaunchKernelGGL(shard_slab_map_kernel, dim3((unsigned)ceil_div64(threads, 256)), dim3(256), 0, as_stream(stream),
+                     uniq_ids, n_uniq, seg_start, perm, n, rows_per_shard, n_shard, cap, msg, slot, oob_flag);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}

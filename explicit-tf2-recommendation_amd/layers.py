@@ -153,6 +153,22 @@ class Embedding(Layer):
         return None
 
 
+def make_embedding(feature_dims, embedding_dims, sharded=False, group=None, comm=None, capacity=None,
+                   embeddings_regularizer=None):
+    """The table of a layer: layers.Embedding, or -- ``sharded=True`` -- sharded.ShardedEmbedding, its rows
+    block-partitioned over the ranks of ``group`` (where the reference builds tf.keras.layers.Embedding,
+    2.FM/CustomLayers.py:176-178, 3.DCN/CustomLayers.py:231, 5.DIN/CustomLayers.py:216-217).  Same call signature;
+    the parameter is ``embeddings_shard`` [ceil(V/P), E] instead of ``embeddings`` [V, E]."""
+    if not sharded:
+        return Embedding(feature_dims, embedding_dims, embeddings_regularizer=embeddings_regularizer)
+    from . import sharded as _sh
+    return _sh.ShardedEmbedding(feature_dims, embedding_dims, group=group, comm=comm, capacity=capacity)
+
+
+def _is_sharded(embed):
+    return hasattr(embed, "embeddings_shard")
+
+
 class MLPLayer(Layer):
     """MatMul + BiasAdd + activation on EVERY layer (2.FM/CustomLayers.py:72-84)."""
 
@@ -249,14 +265,15 @@ class DeepFMRankingLayer(_FMTables, Layer):
 
 class DSSMSingleTowerLayer(Layer):
     def __init__(self, feature_names=["item_tag1", "item_tag2", "item_tag3"], feature_dims=20, embedding_dims=8,
-                 mlp_dims=[64, 32], final_dim=8, **kwargs):
+                 mlp_dims=[64, 32], final_dim=8, sharded=False, group=None, comm=None, capacity=None, **kwargs):
         super().__init__()
         self.feature_names = feature_names
         self.feature_dims = feature_dims
         self.embedding_dims = embedding_dims
         self.mlp_dims = mlp_dims
         self.final_dim = final_dim
-        self.embed = Embedding(feature_dims, embedding_dims, embeddings_regularizer="l2")
+        # sharded=True: the table is row-sharded over the process group (BASELINE config D: 100M x 64d over 8 GPUs)
+        self.embed = make_embedding(feature_dims, embedding_dims, sharded, group, comm, capacity, "l2")
         self.mlp = MLPLayer(units=list(mlp_dims), activation="relu", input_dim=len(feature_names) * embedding_dims)
         self.final = MLPLayer(units=[final_dim], activation=None, input_dim=list(mlp_dims)[-1])
 
@@ -276,12 +293,16 @@ class DSSMTwoTowerRetrievalLayer(Layer):
     def __init__(self, u_feature_names=["user_tag1", "user_tag2"],
                  i_feature_names=["item_tag1", "item_tag2", "item_tag3"], u_feature_dims=20, i_feature_dims=20,
                  u_embedding_dims=8, i_embedding_dims=8, u_mlp_dims=[64, 32], i_mlp_dims=[64, 32], final_dim=8,
-                 **kwargs):
+                 sharded=False, group=None, comm=None, u_capacity=None, i_capacity=None, **kwargs):
         super().__init__()
+        # sharded: True (both towers' tables), or "u" / "i" / ("u", "i")
+        which = ("u", "i") if sharded is True else ((sharded,) if isinstance(sharded, str) else tuple(sharded or ()))
         self.u_tower = DSSMSingleTowerLayer(feature_names=u_feature_names, feature_dims=u_feature_dims,
-                                            embedding_dims=u_embedding_dims, mlp_dims=u_mlp_dims, final_dim=final_dim)
+                                            embedding_dims=u_embedding_dims, mlp_dims=u_mlp_dims, final_dim=final_dim,
+                                            sharded="u" in which, group=group, comm=comm, capacity=u_capacity)
         self.i_tower = DSSMSingleTowerLayer(feature_names=i_feature_names, feature_dims=i_feature_dims,
-                                            embedding_dims=i_embedding_dims, mlp_dims=i_mlp_dims, final_dim=final_dim)
+                                            embedding_dims=i_embedding_dims, mlp_dims=i_mlp_dims, final_dim=final_dim,
+                                            sharded="i" in which, group=group, comm=comm, capacity=i_capacity)
 
     def forward(self, inputs):
         u_embedding = self.u_tower(inputs)["output"]
@@ -429,7 +450,7 @@ class DeepCrossNetworkLayer(Layer):
                                              "itag3", "itag4"],
                  continuous_features=["itag4_origin", "itag4_square", "itag4_cube"], feature_dims=160000,
                  embedding_dims=16, units=[64, 8], activation="relu", layer_num=3, reg_w=1e-4, reg_b=1e-4,
-                 type="vec"):
+                 type="vec", sharded=False, group=None, comm=None, capacity=None):
         super().__init__()
         D = len(continuous_features) + len(categorical_features) * embedding_dims
         if type == "vec":
@@ -437,7 +458,7 @@ class DeepCrossNetworkLayer(Layer):
         else:
             self.cross_layer = MatrixCrossLayer(layer_num, reg_w, reg_b, input_dim=D)
         self.dense_layer = DenseLayer(units, activation, input_dim=D)
-        self.embedding_layer = Embedding(feature_dims, embedding_dims)
+        self.embedding_layer = make_embedding(feature_dims, embedding_dims, sharded, group, comm, capacity)
         self.categorical_features = categorical_features
         self.continuous_features = continuous_features
         self.output_layer = Dense(1, activation="sigmoid", input_dim=D + list(units)[-1])
@@ -655,7 +676,8 @@ class DINLayer(Layer):
                  item_categorical_features=["i_goods_id", "i_shop_id", "i_cate_id"],
                  behavior_series_features=["visited_goods_ids", "visited_shop_ids", "visited_cate_ids"],
                  continuous_features=["itag4_origin", "itag4_square", "itag4_cube"], feature_dims=160000,
-                 embedding_dims=16, activation="Dice", padding_index=0, mask_mode="reference"):
+                 embedding_dims=16, activation="Dice", padding_index=0, mask_mode="reference", sharded=False, group=None,
+                 comm=None, capacity=None):
         super().__init__()
         self.user_and_context_categorical_features = user_and_context_categorical_features
         self.item_categorical_features = item_categorical_features
@@ -668,7 +690,11 @@ class DINLayer(Layer):
         if mask_mode not in ("reference", "valid"):
             raise ValueError("mask_mode must be 'reference' or 'valid'")
         self.mask_mode = mask_mode
-        self.embed = Embedding(feature_dims, embedding_dims)
+        if sharded and padding_index != 0:
+            raise NotImplementedError("sharded DINLayer: padding_index must be 0 (the smallest id: its row then sits in "
+                                      "slot 0 of the exchanged rows, which is what the attention kernel's mask compares)")
+        # sharded=True: the table is row-sharded over the process group (BASELINE config E: 50M x 32d over 8 GPUs)
+        self.embed = make_embedding(feature_dims, embedding_dims, sharded, group, comm, capacity)
         D = len(item_categorical_features) * embedding_dims
         self.din_activation_layer = DinActivationLayer(
             activation=Dice() if activation == "Dice" else activation, input_dim=D)
@@ -677,31 +703,54 @@ class DINLayer(Layer):
                                   input_dim=n_profile * embedding_dims + D)
         self.padding_index = padding_index
 
+    def _series(self, inputs, device):
+        series_cols = []
+        for name in self.behavior_series_features:
+            t = inputs[name]
+            if not isinstance(t, torch.Tensor):
+                t = torch.as_tensor(t)
+            t = t.to(device=device, dtype=torch.int64).contiguous()
+            if t.dim() != 2:
+                raise ValueError("behaviour series %r must have shape [B,T]" % name)
+            series_cols.append(t)
+        B, T = series_cols[0].shape
+        return ops.index_pack(series_cols).reshape(B, T, len(series_cols))        # tf.stack(axis=2)
+
     def forward(self, inputs):
         prof_names = self.user_and_context_categorical_features + self.item_categorical_features
         X_cate = assemble_index(inputs, prof_names)
         flag = ops.new_flag(X_cate.device) if self.check_ids else None
+        n_item = len(self.item_categorical_features)
+        mask_valid = 1 if self.mask_mode == "valid" else 0
+        if _is_sharded(self.embed):
+            # row-sharded table: ONE de-duplicated exchange for the profile ids, the behaviour series and the padding id
+            # (always part of the lookup: as the smallest id it is unique 0 of owner 0 = slot 0 of the rows that come
+            # back, so the attention kernel's mask `first series id == padding_index` becomes `slot == 0`); every
+            # consumer then works on the local [P*cap, E] rows buffer with slots in place of ids
+            series = self._series(inputs, X_cate.device)
+            pad = torch.full((1,), self.padding_index, dtype=torch.int64, device=X_cate.device)
+            n1, n2 = X_cate.numel(), series.numel()
+            rows, slot = self.embed.exchange(torch.cat([X_cate.reshape(-1), series.reshape(-1), pad]), flag)
+            s_cate = slot[:n1].reshape(X_cate.shape).contiguous()
+            s_series = slot[n1:n1 + n2].reshape(series.shape).contiguous()
+            sink = self.embed.grad_sink(X_cate)
+            profile = Fn.Gather.apply(rows, s_cate, None, sink)
+            profile_output = profile.reshape(profile.shape[0], -1)
+            q = profile[:, profile.shape[1] - n_item:, :].reshape(profile.shape[0], -1)
+            pooled, _ = self.din_activation_layer.attend(rows, q, s_series, 0, mask_valid, None, sink)
+            self._raise_if_oob(flag)
+            X_combined = ConcatCols.apply(profile_output, pooled)
+            return {"output": self.mlp(X_combined)}
         # one lookup serves both: the candidate item's rows are the tail of the profile rows (the reference looks the
         # item ids up a second time, 5.DIN/CustomLayers.py:244-247 -- same values), and the series lookups of the
         # attention share the profile lookup's de-duplication (functional.GradSink)
         sink = self.embed.grad_sink(X_cate)
         profile = self.embed(X_cate, flag, sink)
         profile_output = profile.reshape(profile.shape[0], -1)
-        n_item = len(self.item_categorical_features)
         q = profile[:, profile.shape[1] - n_item:, :].reshape(profile.shape[0], -1)
-        series_cols = []
-        for name in self.behavior_series_features:
-            t = inputs[name]
-            if not isinstance(t, torch.Tensor):
-                t = torch.as_tensor(t)
-            t = t.to(device=X_cate.device, dtype=torch.int64).contiguous()
-            if t.dim() != 2:
-                raise ValueError("behaviour series %r must have shape [B,T]" % name)
-            series_cols.append(t)
-        B, T = series_cols[0].shape
-        series = ops.index_pack(series_cols).reshape(B, T, len(series_cols))      # tf.stack(axis=2)
+        series = self._series(inputs, X_cate.device)
         pooled, _ = self.din_activation_layer.attend(self.embed.embeddings, q, series, self.padding_index,
-                                                     1 if self.mask_mode == "valid" else 0, flag, sink)
+                                                     mask_valid, flag, sink)
         self._raise_if_oob(flag)
         X_combined = ConcatCols.apply(profile_output, pooled)
         return {"output": self.mlp(X_combined)}

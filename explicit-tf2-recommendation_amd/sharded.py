@@ -6,10 +6,11 @@ not be replicated on) one GPU: 100M x 64d = 25.6 GB per tower at BASELINE config
 so all-to-all is the natural collective (one hop, all 7 links busy).
 
     block partition:  rows_per_shard = ceil(V / P),  owner = id // rows_per_shard,  local = id - owner*rows_per_shard
-    forward   C1  all-to-all of per-owner id counts, then of the ids themselves (int64)
+    forward   --  de-duplicate the batch's ids (sorted-unique plan; ascending = grouped by owner)
+              C1  all-to-all of fixed-capacity id slabs (no count exchange, nothing read back by the host)
               --  local gather on the owner (HIP gather kernel)
-              C2  all-to-all of the gathered rows back to the requesters, inverse permutation
-    backward  C3  all-to-all of the row gradients to the owners, who de-duplicate and segment-sum them
+              C2  all-to-all of the gathered rows back to the requesters (row = owner*cap + rank: no permutation)
+    backward  C3  all-to-all of the per-unique-id row gradients to the owners, who add the P ascending lists
 
 The integer side (bucketize / permutation / counts) is bit exact and independent of P; tests/test_sharded.py holds
 ``lookup == table[ids]`` bitwise for P in {1,2,4,8} logical shards on one device and for a 2-rank gloo group.
@@ -21,10 +22,11 @@ from . import ops
 
 
 class HipBackend:
-    """The device-side pieces, all HIP kernels (ops.py).  Tests on CPU inject an oracle-backed stand-in."""
+    """The device-side pieces, all HIP kernels on the current stream (ops.py / the C ABI); nothing here reads a value back
+    to the host.  Tests on CPU inject an oracle-backed stand-in with the same methods; the product never does."""
 
     @staticmethod
-    def bucketize(ids, rows_per_shard, n_shard):
+    def bucketize(ids, rows_per_shard, n_shard):                 # (LocalShards: P logical shards in one process)
         flag = ops.new_flag(ids.device)
         perm, counts, local = ops.shard_bucketize(ids, rows_per_shard, n_shard, flag)
         return perm, counts, local, flag
@@ -38,10 +40,56 @@ class HipBackend:
         return ops.permute_rows(x, perm, scatter)
 
     @staticmethod
-    def dedup_sum(ids, vals, V):
-        """(uniq_ids [n], rows [n,E], n_uniq [1]) with the padded-tail convention of ops.DedupPlan."""
-        plan = ops.DedupPlan(ids, V)
-        return plan.uniq_ids, plan.segment_sum(vals, vals.shape[1]), plan.n_uniq
+    def plan(ids, V):
+        """Sorted-unique plan of the flat id list (own LSD radix sort, graph-safe): .uniq_ids / .seg_start / .perm /
+        .n_uniq, padded tails."""
+        return ops.DedupPlan(ids, V)
+
+    @staticmethod
+    def slab_map(plan, n, rows_per_shard, n_shard, cap, flag):
+        """msg [P, 2+cap] (count, 0, owner-local ids ascending) and slot [n] (row of every lookup in the [P*cap, E]
+        buffer the rows come back in): rec_shard_slab_map_i64."""
+        dev = plan.uniq_ids.device
+        msg = torch.zeros((n_shard, cap + 2), dtype=torch.int64, device=dev)
+        slot = torch.empty(n, dtype=torch.int64, device=dev)
+        ops.check(ops.lib.rec_shard_slab_map_i64(ops._ptr(plan.uniq_ids), ops._ptr(plan.n_uniq), ops._ptr(plan.seg_start),
+                                                 ops._ptr(plan.perm), n, rows_per_shard, n_shard, cap, ops._ptr(msg),
+                                                 ops._ptr(slot), ops._ptr(flag), ops._stream()), "rec_shard_slab_map_i64")
+        return msg, slot
+
+    @staticmethod
+    def gather_lists(table, msg, n_shard, cap, flag):
+        """Owner side: rows of the ids every rank asked for, [P*cap, E]; slots beyond a list's count are not touched."""
+        V, E = table.shape
+        out = torch.zeros((n_shard * cap, E), dtype=torch.float32, device=table.device)
+        ops.check(ops.lib.rec_emb_gather_lists_f32(ops._ptr(table), V, E, table.stride(0), ops._ptr(msg), n_shard, cap,
+                                                   ops._ptr(out), ops._ptr(flag), ops._stream()), "rec_emb_gather_lists_f32")
+        return out
+
+    @staticmethod
+    def take_rows(rows, slots, sink):
+        """out[i] = rows[slots[i]] with a sparse (de-duplicated) gradient for `rows`: the ordinary gather of layers.py on
+        the local [P*cap, E] buffer."""
+        from . import functional as Fn
+        return Fn.Gather.apply(rows, slots, None, sink)
+
+    @staticmethod
+    def owner_reduce(msg, g_rows, n_shard, cap, rows_per_shard):
+        """Union of the P ascending id lists that arrived (rank merge, no sort) and the row sums in its order:
+        (uniq local ids [P*cap], rows [P*cap, E], n_uniq [1]); tails padded (valid id, zero rows)."""
+        m, E = g_rows.shape
+        dev = g_rows.device
+        uniq = torch.empty(m, dtype=torch.int64, device=dev)
+        seg = torch.empty(m + 1, dtype=torch.int32, device=dev)
+        perm = torch.empty(m, dtype=torch.int32, device=dev)
+        nu = torch.zeros(1, dtype=torch.int64, device=dev)
+        nbytes = ops.lib.rec_dedup_workspace_bytes(m)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ops.check(ops.lib.rec_dedup_plan_sorted_slabs_i64(ops._ptr(msg), n_shard, cap, rows_per_shard, ops._ptr(uniq),
+                                                          ops._ptr(seg), ops._ptr(perm), ops._ptr(nu), ops._ptr(ws), nbytes,
+                                                          ops._stream()), "rec_dedup_plan_sorted_slabs_i64")
+        rows = ops.tops.segment_sum(g_rows.contiguous(), E, perm, seg, m, 1)
+        return uniq, rows, nu
 
 
 class DistComm:
@@ -111,49 +159,69 @@ class HostStagedComm(DistComm):
         return x
 
 
-class _Lookup(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, local_table, ids, emb):
-        be, comm = emb.backend, emb.comm
-        flat = ids.reshape(-1).contiguous()
-        perm, counts, local_ids, flag = be.bucketize(flat, emb.rows_per_shard, comm.world)
-        send = counts.tolist()                                   # host sync: RCCL needs the split sizes
-        if flag is not None and int(flag.item()) != 0:
-            raise IndexError("embedding id out of range [0, %d)" % emb.num_embeddings)
-        recv = comm.exchange_counts(counts).tolist()             # C1 (counts)
-        their_ids = comm.all_to_all(local_ids, send, recv)       # C1 (ids I must serve)
-        rows = be.gather(local_table, their_ids)                 # local HIP gather
-        back = comm.all_to_all(rows, recv, send)                 # C2
-        out = be.permute_rows(back, perm, True)                  # out[perm[i]] = back[i]
-        ctx.save_for_backward(perm, their_ids)
-        ctx.meta = (emb, send, recv, tuple(local_table.shape))
-        return out.reshape(tuple(ids.shape) + (local_table.shape[1],))
+class _Exchange(torch.autograd.Function):
+    """ids -> (rows [P*cap, E], slot [n]): de-duplicate first, then exchange in FIXED-CAPACITY slabs -- constant split
+    sizes, so no count exchange, nothing read back by the host, every shape known before the call: the whole lookup (and
+    its backward) is a fixed program that engine.GraphedTrainStep captures in a hipGraph.
+
+        plan     sorted-unique plan of the flat ids; ascending = already grouped by owner (block partition)
+        map      rec_shard_slab_map_i64: owner o's slab of the id message, every lookup's slot o*cap + rank
+        C1       all-to-all of the id messages [P, 2+cap] (own communicator)          -- skipped at world size 1
+                 owner-side gather of the requested rows -> [P*cap, E]
+        C2       all-to-all of the rows back: row o*cap + j = the j-th id this rank asked owner o for
+      backward   the consumers' (sparse, de-duplicated) gradient of the rows buffer is laid out dense [P*cap, E],
+        C3       travels to the owners, who add the P lists in the order of their union (rank merge, no sort)
+    """
 
     @staticmethod
-    def backward(ctx, g):
-        perm, their_ids = ctx.saved_tensors
-        emb, send, recv, shape = ctx.meta
+    def forward(ctx, shard, ids, emb, flag):
         be, comm = emb.backend, emb.comm
-        E = shape[1]
-        g = g.contiguous().reshape(-1, E)
-        g_sorted = be.permute_rows(g, perm, False)               # g_sorted[i] = g[perm[i]]
-        g_theirs = comm.all_to_all(g_sorted, send, recv)         # C3
-        if their_ids.numel() == 0:
-            return torch.sparse_coo_tensor(torch.zeros((1, 0), dtype=torch.int64, device=g.device),
-                                           g.new_zeros((0, E)), shape), None, None
-        uniq, rows, _ = be.dedup_sum(their_ids, g_theirs, shape[0])
-        grad = torch.sparse_coo_tensor(uniq[: rows.shape[0]].unsqueeze(0), rows, shape)
-        return grad, None, None
+        P, rps = comm.world, emb.rows_per_shard
+        n = ids.numel()
+        cap = emb.capacity_for(n)
+        plan = be.plan(ids, P * rps)
+        msg, slot = be.slab_map(plan, n, rps, P, cap, flag)
+        msg_theirs = comm.exchange_ids(msg, torch.empty_like(msg)) if P > 1 else msg          # C1
+        rows_out = be.gather_lists(shard, msg_theirs, P, cap, flag)
+        rows = comm.exchange(rows_out, torch.empty_like(rows_out)) if P > 1 else rows_out     # C2
+        ctx.save_for_backward(msg_theirs)
+        ctx.meta = (emb, cap, tuple(shard.shape))
+        ctx.mark_non_differentiable(slot)
+        return rows, slot
+
+    @staticmethod
+    def backward(ctx, g, _gslot):
+        (msg_theirs,) = ctx.saved_tensors
+        emb, cap, shape = ctx.meta
+        be, comm = emb.backend, emb.comm
+        P = comm.world
+        if g.is_sparse:
+            # (uniq slots, row sums) of the consumers' de-duplication; its padded tail repeats a valid slot with zero rows,
+            # so adding is exact whatever the order
+            dense = torch.zeros((P * cap, shape[1]), dtype=torch.float32, device=g.device)
+            dense.index_add_(0, g._indices()[0], g._values())
+            g = dense
+        g = g.contiguous()
+        g_theirs = comm.exchange(g, torch.empty_like(g)) if P > 1 else g                       # C3
+        uniq, rows, _ = be.owner_reduce(msg_theirs, g_theirs, P, cap, emb.rows_per_shard)
+        return torch.sparse_coo_tensor(uniq[: rows.shape[0]].unsqueeze(0), rows, shape), None, None, None
 
 
 class ShardedEmbedding(torch.nn.Module):
-    """Embedding(V, E) whose rows are block-partitioned over the ranks of ``group``; this rank holds
-    ``embeddings_shard`` [rows_per_shard, E] = global rows [rank*rows_per_shard, ...)."""
+    """Embedding(V, E) whose rows are block-partitioned over the ranks of ``group``: this rank holds
+    ``embeddings_shard`` [rows_per_shard, E] = global rows [rank*rows_per_shard, ...).  Plugs in where the reference
+    builds ``tf.keras.layers.Embedding`` (2.FM/CustomLayers.py:176-178, 5.DIN/CustomLayers.py:216-217): ``forward(X, oob,
+    sink)`` has the call signature of layers.Embedding.
+
+    ``capacity``: slots per owner of the fixed-capacity exchange = the most UNIQUE ids one call can hold for one owner.
+    Default min(lookups, rows_per_shard) -- always enough; a caller that knows the field layout passes the tighter
+    engine.exchange_capacity(...) bound (P x capacity rows travel per exchange).  Too small a capacity sets the flag
+    that ``check_flags()`` turns into an IndexError (as an out-of-range id does)."""
 
     def __init__(self, num_embeddings, embedding_dim, group=None, comm=None, backend=None, init_scale=0.05,
-                 seed=1234):
+                 seed=1234, capacity=None):
         super().__init__()
-        self.comm = comm if comm is not None else DistComm(group)
+        self.comm = comm if comm is not None else DistComm(group, separate_count_channel=True)
         self.backend = backend if backend is not None else HipBackend
         self.num_embeddings, self.embedding_dim = num_embeddings, embedding_dim
         P, r = self.comm.world, self.comm.rank
@@ -161,9 +229,17 @@ class ShardedEmbedding(torch.nn.Module):
         lo = min(num_embeddings, r * self.rows_per_shard)
         hi = min(num_embeddings, lo + self.rows_per_shard)
         self.row_range = (lo, hi)
+        self.capacity = capacity
         g = torch.Generator().manual_seed(seed + r)
         shard = (torch.rand((self.rows_per_shard, embedding_dim), generator=g) * 2 - 1) * init_scale
         self.embeddings_shard = torch.nn.Parameter(shard)
+        self.flag = None                                         # device int32: overflow / out-of-range, set by the kernels
+
+    def capacity_for(self, n):
+        cap = min(int(n), self.rows_per_shard)
+        if self.capacity is not None:
+            cap = min(cap, int(self.capacity))
+        return max(cap, 1)
 
     def load_global_rows(self, table):
         """Copy this rank's block out of a full [V,E] table (tests / checkpoint import)."""
@@ -172,8 +248,31 @@ class ShardedEmbedding(torch.nn.Module):
             self.embeddings_shard.zero_()
             self.embeddings_shard[: hi - lo].copy_(table[lo:hi])
 
-    def forward(self, ids):
-        return _Lookup.apply(self.embeddings_shard, ids, self)
+    def grad_sink(self, X):
+        from . import functional as Fn
+        if torch.is_grad_enabled() and self.embeddings_shard.requires_grad:
+            return Fn.GradSink(X.numel())
+        return None
+
+    def exchange(self, ids, oob=None):
+        """(rows [P*cap, E] -- differentiable --, slot [n]) for the flat id list: rows[slot[i]] = table[ids[i]].  For a
+        layer with several lookups into this table (DIN: profile + behaviour series) ONE exchange serves them all."""
+        ids = ids.reshape(-1).contiguous()
+        if oob is None and ids.is_cuda:
+            if self.flag is None:
+                self.flag = torch.zeros(1, dtype=torch.int32, device=ids.device)
+            oob = self.flag
+        return _Exchange.apply(self.embeddings_shard, ids, self, oob)
+
+    def forward(self, X, oob=None, sink=None):
+        rows, slot = self.exchange(X, oob)
+        out = self.backend.take_rows(rows, slot.reshape(X.shape), sink)
+        return out.reshape(tuple(X.shape) + (self.embedding_dim,))
+
+    def check_flags(self):
+        if self.flag is not None and int(self.flag.item()) != 0:
+            raise IndexError("embedding id out of range [0, %d), or more unique ids for one owner than the exchange "
+                             "capacity" % self.num_embeddings)
 
 
 def allreduce_dense_grads(params, group=None):

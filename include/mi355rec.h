@@ -242,6 +242,14 @@ int rec_colsort_shard_map_fixed_i64(const int32_t* perm, const int64_t* col_uid,
                                     const int32_t* col_nu, int64_t B, int F, int64_t rows_per_shard, int n_shard,
                                     int64_t cap, int64_t* msg, int64_t* uidx, int32_t* slot_map, int64_t* n_uniq,
                                     int* oob_flag, void* stream);
+/* The same kind of plan for a GENERIC lookup (any id list, any layer): on top of rec_dedup_plan_i64 of the flat ids
+ * (uniq_ids ascending = grouped by owner under the block partition, seg_start, perm, *n_uniq on the device).
+ * msg [n_shard, 2 + cap] as above (words beyond an owner's count are left alone: the caller keeps them zero);
+ * slot [n] int64: row of every lookup in the [n_shard * cap, E] buffer the rows come back in.  *oob_flag is set when an
+ * owner's unique ids exceed cap or an id lies outside [0, n_shard * rows_per_shard). */
+int rec_shard_slab_map_i64(const int64_t* uniq_ids, const int64_t* n_uniq, const int32_t* seg_start, const int32_t* perm,
+                           int64_t n, int64_t rows_per_shard, int n_shard, int64_t cap, int64_t* msg, int64_t* slot,
+                           int* oob_flag, void* stream);
 /* Owner side of it.  Gather for n_lists received slabs (msg layout above): out [n_lists * cap, E], row (q, j) written
  * only for j < count_q = the first E floats of the table row (E a multiple of 4 up to 256, E <= ld; the sharded
  * DeepFM step sends E = 20 of the 32 floats of a fused row: [embed 16 | w | pad]); 16-byte aligned operands. */

@@ -49,6 +49,80 @@ class OracleBackend:
         r[: len(uniq)] = rows
         return torch.from_numpy(u), torch.from_numpy(r), torch.tensor([len(uniq)])
 
+    # ---- the de-duplicate-first, fixed-capacity exchange (numpy restatement of the kernels' contracts)
+    @staticmethod
+    def plan(ids, V):
+        a = ids.numpy().reshape(-1)
+        n = a.size
+        order = np.argsort(a, kind="stable")
+        srt = a[order]
+        head = np.ones(n, bool)
+        head[1:] = srt[1:] != srt[:-1]
+        uniq = srt[head]
+        nu = len(uniq)
+        seg = np.full(n + 1, n, np.int32)
+        seg[:nu] = np.nonzero(head)[0]
+        u = np.full(max(n, 1), uniq[0] if nu else 0, np.int64)
+        u[:nu] = uniq
+
+        class P_:
+            pass
+        pl = P_()
+        pl.uniq_ids, pl.seg_start = torch.from_numpy(u), torch.from_numpy(seg)
+        pl.perm, pl.n_uniq, pl.n = torch.from_numpy(order.astype(np.int32)), torch.tensor([nu]), n
+        return pl
+
+    @staticmethod
+    def slab_map(plan, n, rows_per_shard, n_shard, cap, flag):
+        nu = int(plan.n_uniq.item())
+        uniq = plan.uniq_ids.numpy()[:nu]
+        msg = np.zeros((n_shard, cap + 2), np.int64)
+        first = np.searchsorted(uniq, np.arange(n_shard + 1) * rows_per_shard)
+        first[-1] = nu
+        uslot = np.zeros(nu, np.int64)
+        for o in range(n_shard):
+            c = first[o + 1] - first[o]
+            assert c <= cap, "exchange capacity exceeded"
+            msg[o, 0] = c
+            msg[o, 2:2 + c] = uniq[first[o]:first[o + 1]] - o * rows_per_shard
+            uslot[first[o]:first[o + 1]] = o * cap + np.arange(c)
+        seg = plan.seg_start.numpy()[:nu]
+        slot = np.empty(n, np.int64)
+        pos_to_u = np.searchsorted(seg, np.arange(n), side="right") - 1
+        slot[plan.perm.numpy()] = uslot[pos_to_u]
+        return torch.from_numpy(msg), torch.from_numpy(slot)
+
+    @staticmethod
+    def gather_lists(table, msg, n_shard, cap, flag):
+        t = table.detach().numpy()
+        out = np.zeros((n_shard * cap, t.shape[1]), np.float32)
+        m = msg.numpy()
+        for q in range(n_shard):
+            c = int(m[q, 0])
+            out[q * cap:q * cap + c] = L.embedding_lookup(t, m[q, 2:2 + c])
+        return torch.from_numpy(out)
+
+    @staticmethod
+    def take_rows(rows, slots, sink):
+        return rows[slots]                                      # torch indexing: dense gradient of the rows buffer
+
+    @staticmethod
+    def owner_reduce(msg, g_rows, n_shard, cap, rows_per_shard):
+        m_, g = msg.numpy(), g_rows.numpy()
+        ids = np.concatenate([m_[q, 2:2 + int(m_[q, 0])] for q in range(n_shard)])
+        vals = np.concatenate([g[q * cap:q * cap + int(m_[q, 0])] for q in range(n_shard)])
+        tot = n_shard * cap
+        u = np.zeros(tot, np.int64)
+        r = np.zeros((tot, g.shape[1]), np.float32)
+        nu = 0
+        if len(ids):
+            uniq, rows = L.dedup_indexed_slices(ids, vals, "sorted")
+            nu = len(uniq)
+            u[:] = uniq[0]
+            u[:nu] = uniq
+            r[:nu] = rows
+        return torch.from_numpy(u), torch.from_numpy(r), torch.tensor([nu])
+
 
 def _free_port():
     s = socket.socket()
@@ -65,7 +139,9 @@ def _worker(rank, world, port, V, E, result):
     try:
         from explicit_tf2_recommendation_amd import sharded
         table = torch.from_numpy(H.rng(0).normal(size=(V, E)).astype(np.float32))
-        emb = sharded.ShardedEmbedding(V, E, backend=OracleBackend)
+        # ranks with different batch sizes agree on the slab size through an explicit capacity (the default,
+        # min(lookups, rows per shard), needs the same number of lookups on every rank)
+        emb = sharded.ShardedEmbedding(V, E, backend=OracleBackend, capacity=100)
         emb.load_global_rows(table)
         r = H.rng(100 + rank)
         ids = torch.from_numpy(np.minimum(r.zipf(1.2, size=(37 + 5 * rank, 3)) - 1, V - 1).astype(np.int64))
@@ -421,4 +497,157 @@ def test_sharded_deepfm_step_two_ranks_hip_kernels_match_single_gpu_global_batch
     mgr = mp.Manager()
     result = mgr.dict()
     mp.spawn(_gpu_step_worker, args=(world, _free_port(), V, B, F, result), nprocs=world, join=True)
+    assert len(result) == world and all(all(v) for v in dict(result).values()), dict(result)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Row-sharded tables behind the layers of BASELINE configs D (DSSM two-tower) and E (DIN): layers.*(sharded=True)
+# ---------------------------------------------------------------------------------------------------
+def _family(family, V, sharded, comm=None, E=8, T=9):
+    from explicit_tf2_recommendation_amd import data, layers
+    kw = dict(sharded=sharded, comm=comm) if sharded else {}
+    if family == "dssm":
+        un, inn = ["user_tag1", "user_tag2"], ["item_tag1", "item_tag2", "item_tag3"]
+        layer = layers.DSSMTwoTowerRetrievalLayer(u_feature_names=un, i_feature_names=inn, u_feature_dims=V,
+                                                  i_feature_dims=V, u_embedding_dims=E, i_embedding_dims=E, **kw)
+        mk = lambda seed: data.SyntheticGenerator(un + inn, V, dist="zipf", seed=seed)
+    elif family == "dcn":
+        cat, cont = ["c%d" % i for i in range(6)], ["x0", "x1"]
+        layer = layers.DeepCrossNetworkLayer(categorical_features=cat, continuous_features=cont, feature_dims=V,
+                                             embedding_dims=E, layer_num=2, type="matrix", **kw)
+        mk = lambda seed: data.SyntheticGenerator(cat, V, continuous=cont, dist="zipf", seed=seed)
+    else:
+        user, item = ["uid", "utag1"], ["i_goods_id", "i_shop_id", "i_cate_id"]
+        ser = ["visited_goods_ids", "visited_shop_ids", "visited_cate_ids"]
+        layer = layers.DINLayer(user_and_context_categorical_features=user, item_categorical_features=item,
+                                behavior_series_features=ser, feature_dims=V, embedding_dims=E,
+                                mask_mode="reference" if family == "din" else "valid", **kw)
+        mk = lambda seed: data.SyntheticGenerator(user + item, V, series=ser, seq_len=T, seed=seed)
+    return layer.cuda(), mk
+
+
+def _tables(layer):
+    """(name, module) of every embedding table of a layer"""
+    return [(n, m) for n, m in layer.named_modules() if hasattr(m, "embeddings") or hasattr(m, "embeddings_shard")]
+
+
+def _copy_into_sharded(ref, sh):
+    """Parameters of the unsharded layer -> the sharded twin (tables: this rank's block of rows)."""
+    rt, st = dict(_tables(ref)), dict(_tables(sh))
+    with torch.no_grad():
+        for n, m in st.items():
+            if hasattr(m, "embeddings_shard"):
+                m.load_global_rows(rt[n].embeddings.detach())
+        rp = dict(ref.named_parameters())
+        for n, p in sh.named_parameters():
+            if not n.endswith("embeddings_shard"):
+                p.copy_(rp[n])
+
+
+def _loss_and_grads(layer, batch):
+    from explicit_tf2_recommendation_amd import functional as Fn
+    for p in layer.parameters():
+        p.grad = None
+    out = layer({k: v for k, v in batch.items() if k != "label"})["output"]
+    y = batch["label"]
+    if out.dim() == 2 and out.shape[1] > 1:
+        y = y.expand(-1, out.shape[1]).contiguous()
+    loss = Fn.KerasBCE.apply(out, y)
+    loss.backward()
+    return out.detach().clone(), loss.item(), {n: (p.grad.to_dense() if p.grad.is_sparse else p.grad).clone()
+                                               for n, p in layer.named_parameters()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["dssm", "dcn", "din", "din_valid"])
+def test_sharded_layers_world1_match_unsharded_and_replay_from_a_graph(family):
+    """layers.*(sharded=True) at world size 1 (the exchange code of N > 1, collectives skipped for the rank's own slab)
+    against the unsharded layer with the same parameters: outputs, loss and every gradient; then the same step captured by
+    engine.GraphedTrainStep -- the fixed-capacity exchange reads nothing back, so forward + backward replay from ONE
+    hipGraph bit-identically to the eager run."""
+    from explicit_tf2_recommendation_amd import data, engine, layers
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        B, V = 160, 3000
+        layers.set_init_seed(7)
+        ref, mk = _family(family, V, False)
+        sh, _ = _family(family, V, True)
+        _copy_into_sharded(ref, sh)
+        gen = mk(3)
+        batches = [data.to_device(gen.batch(B)) for _ in range(3)]
+        for b in batches[:2]:
+            o_ref, l_ref, g_ref = _loss_and_grads(ref, b)
+            o_sh, l_sh, g_sh = _loss_and_grads(sh, b)
+            assert torch.equal(o_ref, o_sh) and l_ref == l_sh           # same rows into the same kernels: bitwise
+            for n, g in g_sh.items():
+                want = g_ref[n.replace("embeddings_shard", "embeddings")]
+                if n.endswith("embeddings_shard"):
+                    g = g[: want.shape[0]]
+                assert (g - want).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item()), n
+        for _, m in _tables(sh):
+            if hasattr(m, "check_flags"):
+                m.check_flags()
+        step = engine.GraphedTrainStep(sh, batches[0])
+        for b in (batches[2], batches[1], batches[2]):
+            loss = step(b).item()
+            _, want_loss, want = _loss_and_grads(ref, b)
+            assert abs(loss - want_loss) <= 1e-6 * max(1.0, abs(want_loss))
+            for n, p in sh.named_parameters():
+                g = p.grad.to_dense() if p.grad.is_sparse else p.grad
+                w = want[n.replace("embeddings_shard", "embeddings")]
+                if n.endswith("embeddings_shard"):
+                    g = g[: w.shape[0]]
+                assert (g - w).abs().max().item() <= 1e-6 * max(1.0, w.abs().max().item()), n
+    finally:
+        dist.destroy_process_group()
+
+
+def _sharded_layer_worker(rank, world, port, family, V, B, result):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from explicit_tf2_recommendation_amd import data, layers, sharded
+        torch.cuda.set_device(0)
+        layers.set_init_seed(13)
+        ref, mk = _family(family, V, False)                 # every rank builds the same full layer (same seed)
+        layers.set_init_seed(13)
+        sh, _ = _family(family, V, True, comm=sharded.HostStagedComm(None, True))
+        _copy_into_sharded(ref, sh)
+        mine = data.to_device(mk(50 + rank).batch(B))
+        o_ref, l_ref, g_ref = _loss_and_grads(ref, mine)
+        o_sh, l_sh, g_sh = _loss_and_grads(sh, mine)
+        ok = [bool(torch.equal(o_ref, o_sh)), l_ref == l_sh]
+        # table gradients: an owner receives BOTH ranks' contributions -> compare with the sum of the unsharded dense
+        # gradients of both ranks' batches, restricted to this rank's block of rows
+        for n, g in g_sh.items():
+            want = g_ref[n.replace("embeddings_shard", "embeddings")]
+            if n.endswith("embeddings_shard"):
+                tot = want.cpu().clone()
+                dist.all_reduce(tot)
+                mod = dict(_tables(sh))[n.rsplit(".", 1)[0]]
+                lo, hi = mod.row_range
+                ok.append(bool((g[: hi - lo].cpu() - tot[lo:hi]).abs().max() <= 1e-6 * max(1.0, tot.abs().max().item())))
+            else:
+                ok.append(bool((g - want).abs().max() <= 1e-6 * max(1.0, want.abs().max().item())))
+        for _, m in _tables(sh):
+            if hasattr(m, "check_flags"):
+                m.check_flags()
+        result[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["dssm", "din"])
+def test_sharded_layers_two_ranks_hip_kernels(family):
+    """Two ranks (two processes on the one GPU, exchanges through host memory: RCCL refuses two ranks on one device) with
+    the HIP kernels: each rank's outputs against the unsharded layer on its own batch, and every owner's table gradient
+    against the sum of both ranks' unsharded gradients."""
+    world, V, B = 2, 3001, 96
+    mgr = mp.Manager()
+    result = mgr.dict()
+    mp.spawn(_sharded_layer_worker, args=(world, _free_port(), family, V, B, result), nprocs=world, join=True)
     assert len(result) == world and all(all(v) for v in dict(result).values()), dict(result)
