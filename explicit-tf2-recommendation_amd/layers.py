@@ -154,7 +154,7 @@ class Embedding(Layer):
 
 
 def make_embedding(feature_dims, embedding_dims, sharded=False, group=None, comm=None, capacity=None,
-                   embeddings_regularizer=None):
+                   embeddings_regularizer=None, device=None):
     """The table of a layer: layers.Embedding, or -- ``sharded=True`` -- sharded.ShardedEmbedding, its rows
     block-partitioned over the ranks of ``group`` (where the reference builds tf.keras.layers.Embedding,
     2.FM/CustomLayers.py:176-178, 3.DCN/CustomLayers.py:231, 5.DIN/CustomLayers.py:216-217).  Same call signature;
@@ -162,7 +162,7 @@ def make_embedding(feature_dims, embedding_dims, sharded=False, group=None, comm
     if not sharded:
         return Embedding(feature_dims, embedding_dims, embeddings_regularizer=embeddings_regularizer)
     from . import sharded as _sh
-    return _sh.ShardedEmbedding(feature_dims, embedding_dims, group=group, comm=comm, capacity=capacity)
+    return _sh.ShardedEmbedding(feature_dims, embedding_dims, group=group, comm=comm, capacity=capacity, device=device)
 
 
 def _is_sharded(embed):

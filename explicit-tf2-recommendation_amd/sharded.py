@@ -196,11 +196,17 @@ class _Exchange(torch.autograd.Function):
         be, comm = emb.backend, emb.comm
         P = comm.world
         if g.is_sparse:
-            # (uniq slots, row sums) of the consumers' de-duplication; its padded tail repeats a valid slot with zero rows,
-            # so adding is exact whatever the order
-            dense = torch.zeros((P * cap, shape[1]), dtype=torch.float32, device=g.device)
-            dense.index_add_(0, g._indices()[0], g._values())
-            g = dense
+            # (uniq slots, row sums) of the consumers' de-duplication.  Its padded tail repeats the first slot with zero rows:
+            # exact to add, but hundreds of thousands of atomic adds onto ONE row (DIN: half of 1.2 M lookups are the padding
+            # id) took 20 ms -- zero rows that repeat the first slot are dealt out over 8192 scratch rows behind the buffer
+            idx, vals = g._indices()[0], g._values()
+            tail = (idx == idx[:1]) & (vals.abs().amax(dim=1) == 0)
+            tail[:1].zero_()                                        # (in place on the device: capturable)
+            spread = P * cap + (torch.arange(idx.numel(), device=idx.device) & 8191)
+            idx = torch.where(tail, spread, idx)
+            dense = torch.zeros((P * cap + 8192, shape[1]), dtype=torch.float32, device=g.device)
+            dense.index_add_(0, idx, vals)
+            g = dense[: P * cap]
         g = g.contiguous()
         g_theirs = comm.exchange(g, torch.empty_like(g)) if P > 1 else g                       # C3
         uniq, rows, _ = be.owner_reduce(msg_theirs, g_theirs, P, cap, emb.rows_per_shard)
@@ -219,7 +225,7 @@ class ShardedEmbedding(torch.nn.Module):
     that ``check_flags()`` turns into an IndexError (as an out-of-range id does)."""
 
     def __init__(self, num_embeddings, embedding_dim, group=None, comm=None, backend=None, init_scale=0.05,
-                 seed=1234, capacity=None):
+                 seed=1234, capacity=None, device=None):
         super().__init__()
         self.comm = comm if comm is not None else DistComm(group, separate_count_channel=True)
         self.backend = backend if backend is not None else HipBackend
@@ -230,8 +236,14 @@ class ShardedEmbedding(torch.nn.Module):
         hi = min(num_embeddings, lo + self.rows_per_shard)
         self.row_range = (lo, hi)
         self.capacity = capacity
-        g = torch.Generator().manual_seed(seed + r)
-        shard = (torch.rand((self.rows_per_shard, embedding_dim), generator=g) * 2 - 1) * init_scale
+        if device is not None and torch.device(device).type == "cuda":
+            # a large shard is drawn on the device (a host-side torch.rand of 25.6 GB takes minutes)
+            g = torch.Generator(device=device).manual_seed(seed + r)
+            shard = torch.empty((self.rows_per_shard, embedding_dim), dtype=torch.float32, device=device)
+            shard.uniform_(-init_scale, init_scale, generator=g)
+        else:
+            g = torch.Generator().manual_seed(seed + r)
+            shard = (torch.rand((self.rows_per_shard, embedding_dim), generator=g) * 2 - 1) * init_scale
         self.embeddings_shard = torch.nn.Parameter(shard)
         self.flag = None                                         # device int32: overflow / out-of-range, set by the kernels
 

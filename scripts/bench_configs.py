@@ -119,6 +119,40 @@ def run(name):
         dt = timed(fwd_bwd(layer, batch, un + inn), 3, 20)
         return {"config": "D DSSM two-tower, item table 100M x 64d (25.6 GB) on one GPU", "B": B, "V": V,
                 "ms_per_step": dt * 1e3, "examples_per_s": B / dt}
+    if name in ("DS", "ES"):
+        # configs D / E with their tables ROW-SHARDED (layers.*(sharded=True): de-duplicated fixed-capacity exchange) at
+        # world size 1 -- the exchange code of N > 1 with the rank's own slab kept out of RCCL; target <= 1.3 x D / E
+        import torch.distributed as dist
+        from explicit_tf2_recommendation_amd import sharded
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29591")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        if name == "DS":
+            un, inn = ["user_tag1", "user_tag2"], ["item_tag1", "item_tag2", "item_tag3"]
+            V, B, E = 100_000_000, 8192, 64
+            layer = layers.DSSMTwoTowerRetrievalLayer(u_feature_names=un, i_feature_names=inn, u_feature_dims=1000,
+                                                      i_feature_dims=1000, u_embedding_dims=E, i_embedding_dims=E).cuda()
+            layer.i_tower.embed = sharded.ShardedEmbedding(V, E, device="cuda")
+            layer.u_tower.embed = sharded.ShardedEmbedding(V // 10, E, device="cuda")
+            gi = data.SyntheticGenerator(inn, V, seed=0).batch(B)
+            gu = data.SyntheticGenerator(un, V // 10, seed=1).batch(B)
+            batch = data.to_device({**{k: gu[k] for k in un}, **{k: gi[k] for k in inn}, "label": gi["label"]})
+            dt = timed(fwd_bwd(layer, batch, un + inn), 3, 20)
+            return {"config": "DS DSSM two-tower, item table 100M x 64d row-sharded (world size 1)", "B": B, "V": V,
+                    "ms_per_step": dt * 1e3, "examples_per_s": B / dt}
+        user = ["uid", "utag1", "utag2", "utag3", "utag4"]
+        item = ["i_goods_id", "i_shop_id", "i_cate_id"]
+        ser = ["visited_goods_ids", "visited_shop_ids", "visited_cate_ids"]
+        V, B, E, T = 50_000_000, 4096, 32, 100
+        layer = layers.DINLayer(user_and_context_categorical_features=user, item_categorical_features=item,
+                                behavior_series_features=ser, feature_dims=1000, embedding_dims=E).cuda()
+        layer.embed = sharded.ShardedEmbedding(V, E, device="cuda")
+        layer.feature_dims = V
+        batch = data.to_device(data.SyntheticGenerator(user + item, V, series=ser, seq_len=T, seed=0).batch(B))
+        dt = timed(fwd_bwd(layer, batch, user + item + ser), 2, 10)
+        return {"config": "ES DIN T=100, 50M x 32d row-sharded (world size 1)", "B": B, "V": V, "ms_per_step": dt * 1e3,
+                "examples_per_s": B / dt}
     if name == "E":
         user = ["uid", "utag1", "utag2", "utag3", "utag4"]
         item = ["i_goods_id", "i_shop_id", "i_cate_id"]
@@ -200,7 +234,7 @@ if __name__ == "__main__":
     GRAPHED = "--graphed" in sys.argv[1:]
     for n in (argv or ["A", "B", "C", "C26", "D", "E", "R", "P", "N", "FF", "G"]):
         r = run(n)
-        if GRAPHED and n in ("B", "C", "C26", "D", "E", "P", "N", "FF", "G"):
+        if GRAPHED and n in ("B", "C", "C26", "D", "E", "DS", "ES", "P", "N", "FF", "G"):
             r["config"] += " [GraphedTrainStep]"
         r["n_gpus"] = 1
         print(json.dumps(r), flush=True)

@@ -206,22 +206,15 @@ def test_dssm_two_tower_e64_sharded_tables_at_config_d(R):
     os.environ["MASTER_PORT"] = str(_free_port())
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        layer = R.layers.DSSMTwoTowerRetrievalLayer(u_feature_names=un, i_feature_names=inn, u_feature_dims=1000,
-                                                    i_feature_dims=1000, u_embedding_dims=E, i_embedding_dims=E).cuda()
-
-        class ShardedLookup(torch.nn.Module):
-            def __init__(self, emb):
-                super().__init__()
-                self.emb = emb
-
-            def forward(self, X, oob=None):
-                return self.emb(X)
-
+        # the product path: the reference's constructor plus sharded=True (layers.make_embedding -> sharded.ShardedEmbedding)
+        layer = R.layers.DSSMTwoTowerRetrievalLayer(u_feature_names=un, i_feature_names=inn, u_feature_dims=Vu,
+                                                    i_feature_dims=Vi, u_embedding_dims=E, i_embedding_dims=E,
+                                                    sharded=True).cuda()
         tabs = {}
         for tower, p, V in (("u_tower", pu, Vu), ("i_tower", pi, Vi)):
-            emb = sharded.ShardedEmbedding(V, E).cuda()
+            emb = getattr(layer, tower).embed
+            assert isinstance(emb, sharded.ShardedEmbedding)
             emb.load_global_rows(dev(p["embed"]))
-            getattr(layer, tower).embed = ShardedLookup(emb)
             tabs[tower] = emb
             t = getattr(layer, tower)
             with torch.no_grad():
@@ -257,6 +250,68 @@ def test_dssm_two_tower_e64_sharded_tables_at_config_d(R):
             assert close(grad_np(t.mlp.kernel_1), tp["mlp_k"][1].grad.numpy(), 2e-5)
             assert close(grad_np(t.final.kernel_0), tp["final_k"][0].grad.numpy(), 2e-5)
             assert close(grad_np(t.final.bias_0), tp["final_b"][0].grad.numpy(), 2e-5)
+        for emb in tabs.values():
+            emb.check_flags()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_din_layer_over_a_sharded_table_at_config_e_shape(R):
+    """BASELINE config E's "sharded embeddings" half: DINLayer(sharded=True) at T = 100, E = 32 (5 user + 3 item + 3
+    series features), B = 64, against the oracle on the full table -- ONE de-duplicated exchange serves the profile ids,
+    the 100-step behaviour series and the padding id; the attention kernel then runs on the rows that came back with
+    slots in place of ids (both mask conventions)."""
+    import torch.distributed as dist
+    from explicit_tf2_recommendation_amd import sharded
+    from tests.test_gpu_din import _load_din
+    user = ["uid", "utag1", "utag2", "utag3", "utag4"]
+    item = ["i_goods_id", "i_shop_id", "i_cate_id"]
+    ser = ["visited_goods_ids", "visited_shop_ids", "visited_cate_ids"]
+    V, E, B, T_ = 5000, 32, 64, 100
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for mode in ("valid", "reference"):
+            pr = H.din_params(71, V, E, act="dice")
+            ref = R.layers.DINLayer(user_and_context_categorical_features=user, item_categorical_features=item,
+                                    behavior_series_features=ser, feature_dims=V, embedding_dims=E, activation="Dice",
+                                    padding_index=0, mask_mode=mode).cuda()
+            _load_din(ref, pr, "Dice")
+            layer = R.layers.DINLayer(user_and_context_categorical_features=user, item_categorical_features=item,
+                                      behavior_series_features=ser, feature_dims=V, embedding_dims=E, activation="Dice",
+                                      padding_index=0, mask_mode=mode, sharded=True).cuda()
+            assert isinstance(layer.embed, sharded.ShardedEmbedding)
+            sd = dict(ref.named_parameters()); sd.update(dict(ref.named_buffers()))
+            with torch.no_grad():
+                layer.embed.load_global_rows(ref.embed.embeddings.detach())
+                for n, q in list(layer.named_parameters()) + list(layer.named_buffers()):
+                    if not n.endswith("embeddings_shard"):
+                        q.copy_(sd[n])
+            r = H.rng(72)
+            ins = {n: r.integers(1, V, size=(B, 1)).astype(np.int64) for n in user + item}
+            series, _ = _series(r, B, T_, 3, V)
+            for j, n in enumerate(ser):
+                ins[n] = series[:, :, j].copy()
+            out = layer({k: dev(v) for k, v in ins.items()})["output"]
+            layer.embed.check_flags()
+            profile = L.index_assemble(ins, user + item)
+            itm = L.index_assemble(ins, item)
+            tp = H.to_torch(pr, torch.float64, True)
+            o64, _, _ = T.din_forward(tp, torch.from_numpy(profile), torch.from_numpy(itm), torch.from_numpy(series), 0,
+                                      mode)
+            assert np.abs(out.detach().cpu().numpy() - o64.detach().numpy()).max() <= 1e-5, mode
+            y = (r.uniform(size=(B, 1)) < 0.4).astype(np.float32)
+            loss = R.functional.KerasBCE.apply(out, dev(np.repeat(y, 2, axis=1)))
+            loss.backward()
+            lt = T.keras_bce(torch.from_numpy(y).double(), o64)
+            lt.backward()
+            assert abs(loss.item() - lt.item()) <= 1e-5
+            assert close(layer.embed.embeddings_shard.grad.to_dense().cpu().numpy()[:V], tp["embed"].grad.numpy(), 3e-5), mode
+            base = layer.din_activation_layer
+            assert close(base.mlp_layer.layers[0].kernel.grad.cpu().numpy(), tp["att"]["W1"].grad.numpy(), 3e-5)
+            assert close(base.output_layer.kernel.grad.cpu().numpy(), tp["att"]["W2"].grad.numpy(), 3e-5)
+            assert close(layer.mlp.layers[0].kernel.grad.cpu().numpy(), tp["mlp"][0]["K"].grad.numpy(), 3e-5)
     finally:
         dist.destroy_process_group()
 
