@@ -48,9 +48,16 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: REHEARSAL of the multi-rank control flow on a box with fewer GPUs than ranks -- every rank "
                          "uses GPU (local_rank mod device count), exchanges hop through host memory (not a measurement)")
-    ap.add_argument("--sharded-graph", action="store_true",
-                    help="row-sharded step: capture each cycle of steps, RCCL collectives included, in one hipGraph "
-                         "(verified at world size 1 only; the default issues the sharded step eagerly)")
+    ap.add_argument("--sharded-eager", action="store_true",
+                    help="row-sharded step: issue every step eagerly.  The default captures each cycle of steps, RCCL "
+                         "collectives included, in one hipGraph (fixed-capacity exchanges: a fixed program); a capture "
+                         "that fails ends the run with a non-zero exit code, there is no silent fallback")
+    ap.add_argument("--sharded-graph", action="store_true", help="(accepted for compatibility: graphs are the default)")
+    ap.add_argument("--repeats", type=int, default=15,
+                    help="further timed regions of K steps after the reported one, for median / p10 / p90 per step")
+    ap.add_argument("--no-dssm", action="store_true", help="skip the sharded DSSM (config D) scaling record")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary records (Zipf value, B sweep, CrossNet GEMMs, sharded DSSM, optimizers)")
     ap.add_argument("--generic", action="store_true", help="use the generic ~35-kernel step instead of the fused one")
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1: independent full-table replicas instead of the row-sharded table + RCCL all-to-all")
@@ -114,6 +121,147 @@ def cpu_baseline(args, names, seconds):
     return {"value": n * B / el, "unit": "examples/s", "cores": cores, "kind": "port",
             "sample": "%d fwd+bwd steps of the same DeepFM config (B=%d, V=%d) in %.1f s, torch-CPU eager "
                       "op-for-op restatement (oracle/torch_ref.py), %d threads" % (n, B, V, el, cores)}
+
+
+def gather_sweep(lib, check, layer, V, F, E, names, timed):
+    """B sweep of the gather + FM forward kernel (rec_emb_fm_fwd_f32), fresh ids every launch: SURVEY.md section 7's
+    "sweep B to 64 k to show the asymptote".  frac = algorithmic bytes / time / 8 TB/s; frac_lines counts the 128-byte
+    lines actually fetched (one per lookup)."""
+    import ctypes as C
+    from explicit_tf2_recommendation_amd import ops
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    emb, w, bias = layer.embed.embeddings, layer.w.embeddings, layer.bias
+    dims = [V // F] * F
+    dims[-1] += V - sum(dims)
+    offs = np.concatenate([[0], np.cumsum(dims[:-1])])
+    rng = np.random.Generator(np.random.PCG64(5))
+    out = []
+    for Bs in (8192, 16384, 32768, 65536, 131072):
+        nset = max(4, (16 * 8192) // Bs)                  # >= 436 MB of distinct lines between two uses of an id set
+        Xs = [ops.index_pack([torch.from_numpy(rng.integers(0, dims[f], size=Bs) + offs[f]).cuda() for f in range(F)])
+              for _ in range(nset)]
+        z = torch.empty(Bs, dtype=torch.float32, device="cuda")
+
+        def launch(n, Xs=Xs, z=z, Bs=Bs, nset=nset):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            for i in range(n):
+                check(lib.rec_emb_fm_fwd_f32(vp(emb), emb.stride(0), vp(w), w.stride(0), vp(bias), V, E, vp(Xs[i % nset]),
+                                             Bs, F, vp(z), None, None, None, None, st), "rec_emb_fm_fwd_f32")
+
+        us = timed(launch, 2 * nset)
+        n = Bs * F
+        nbytes = n * (8 + 4 * E + 4) + 4 * Bs
+        out.append({"B": Bs, "n_lookups": n, "avg_launch_us": us, "G_lookups_per_s": n / us / 1e3,
+                    "frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                    "frac_lines": n * 128 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS})
+        del Xs
+    torch.cuda.empty_cache()
+    return out
+
+
+def crossnet_record(ops, timed):
+    """fp32 MFMA utilisation of the three GEMMs of a matrix-mode CrossNet layer (3.DCN/CustomLayers.py:297-305 and its
+    backward) at BASELINE config C: M = 16384 rows, D = 323 (10 categorical fields, the reference default) and D = 835
+    (26 fields).  Live-timed like `roofline`; peak = 157.3 TFLOP/s (fp32 matrix, MI355X_MICROARCH.md)."""
+    PEAK = 157.3
+    out = []
+    M = 16384
+    for D in (323, 835):
+        X = torch.randn((M, D), device="cuda")
+        X0 = torch.randn((M, D), device="cuda")
+        W = torch.randn((D, D), device="cuda") * 0.05
+        bvec = torch.zeros(D, device="cuda")
+        H = torch.randn((M, D), device="cuda")
+        U = torch.empty((M, D), device="cuda")
+        forms = (("fwd X.W^T + cross epilogue x0*(u+b)+x (keeps U)",
+                  lambda: ops.gemm(X, W, False, True, epi=ops.EPI_CROSS, bias=bvec, e0=X0, e1=X, aux=U)),
+                 ("bwd dX = H.W", lambda: ops.gemm(H, W, False, False)),
+                 ("bwd dW = H^T.X (split-K over the batch)", lambda: ops.gemm(H, X, True, False)))
+        for name, fn in forms:
+            def launch(n, fn=fn):
+                for _ in range(n):
+                    fn()
+            us = timed(launch, 20)
+            tf = 2.0 * M * D * D / us / 1e6
+            out.append({"bound": "mfma", "D": D, "M": M, "gemm": name, "avg_launch_us": us, "achieved": tf, "peak": PEAK,
+                        "unit": "TFLOP/s", "frac": tf / PEAK})
+        del X, X0, W, H, U
+    torch.cuda.empty_cache()
+    return out
+
+
+def dssm_record(world, rank, local_rank, barrier, reduce_max):
+    """BASELINE config D as the north star states it: DSSM two-tower (2.FM/CustomLayers.py:208-239), item table 100M x 64d and
+    user table 10M x 64d ROW-SHARDED over the ranks (layers.DSSMTwoTowerRetrievalLayer(sharded=True): de-duplicated
+    fixed-capacity all-to-all of ids / rows / row gradients), dense parameters data-parallel (one flat all-reduce), B = 8192
+    examples per rank (weak scaling), forward + Keras BCE + backward.  N = 1: the whole step replays from one hipGraph (no
+    collective: the rank's own slab stays out of RCCL); N > 1: enqueued eagerly (RCCL inside a captured graph is verified at
+    world size 1 only)."""
+    import torch.distributed as dist
+    from explicit_tf2_recommendation_amd import layers, data, engine, sharded, functional as Fn
+    Vi, Vu, E, Bd = 100_000_000, 10_000_000, 64, 8192
+    un, inn = ["user_tag1", "user_tag2"], ["item_tag1", "item_tag2", "item_tag3"]
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+    old_check = layers.Layer.check_ids
+    layers.Layer.check_ids = False
+    try:
+        layers.set_init_seed(7)
+        layer = layers.DSSMTwoTowerRetrievalLayer(u_feature_names=un, i_feature_names=inn, u_feature_dims=1000,
+                                                  i_feature_dims=1000, u_embedding_dims=E, i_embedding_dims=E).cuda()
+        comm = sharded.DistComm(None, separate_count_channel=True)
+        # per-owner capacity of the exchange from the field layout (engine.exchange_capacity: sum over the fields that meet
+        # the owner's block of min(B, overlap)), as the sharded DeepFM step does
+        def cap(V, nf):
+            dims, offs, _ = data.field_layout(V, nf)
+            return engine.exchange_capacity(dims, offs, Bd, -(-V // world), world)
+        layer.i_tower.embed = sharded.ShardedEmbedding(Vi, E, comm=comm, capacity=cap(Vi, 3), device="cuda")
+        layer.u_tower.embed = sharded.ShardedEmbedding(Vu, E, comm=comm, capacity=cap(Vu, 2), device="cuda")
+        dense = [p for n, p in layer.named_parameters() if "embeddings_shard" not in n]
+        nb = 4
+        bs = []
+        for k in range(nb):
+            gi = data.SyntheticGenerator(inn, Vi, seed=10 * rank + k).batch(Bd)
+            gu = data.SyntheticGenerator(un, Vu, seed=1000 + 10 * rank + k).batch(Bd)
+            bs.append(data.to_device({**{n: gu[n] for n in un}, **{n: gi[n] for n in inn}, "label": gi["label"]}))
+        graphed = world == 1
+        if graphed:
+            gstep = engine.GraphedTrainStep(layer, bs[0])
+            one = lambda i: gstep(bs[i % nb])
+        else:
+            def one(i):
+                b = bs[i % nb]
+                for p in layer.parameters():
+                    p.grad = None
+                out = layer({k: b[k] for k in un + inn})["output"]
+                Fn.KerasBCE.apply(out, b["label"]).backward()
+                sharded.allreduce_dense_grads(dense)
+        for i in range(6):
+            one(i)
+        K = 40
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(K):
+            one(i)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            el = reduce_max(el)
+        for t in (layer.i_tower.embed, layer.u_tower.embed):
+            t.check_flags()
+        rec = {"config": "D: DSSM two-tower, item table 100M x 64d + user table 10M x 64d row-sharded over %d rank(s), "
+                         "fwd + Keras BCE + bwd, B = 8192 per rank" % world,
+               "n_gpus": world, "batch_per_gpu": Bd, "steps": K, "ms_per_step": el / K * 1e3,
+               "value": world * Bd * K / el, "unit": "examples/s", "scaling": "weak",
+               "mode": "one hipGraph per step" if graphed else "eager (RCCL collectives outside graphs)",
+               "exchange_slots_per_owner": {"item": cap(Vi, 3), "user": cap(Vu, 2)}}
+        del layer, bs
+        torch.cuda.empty_cache()
+        return rec
+    finally:
+        layers.Layer.check_ids = old_check
 
 
 def launch_ranks(args):
@@ -229,11 +377,11 @@ def main():
     # launch costs ~20 us of idle GPU); --step-graphs keeps one graph per step
     cycle = (not sharded_mode) and (not args.generic) and (not args.no_graph) and (not args.step_graphs)
 
-    def calls_of(n):
+    def calls_of(n, batches=batches):
         """The calls of one run of n steps, each with the batches it announces as next: every run starts at batch 0, so
         its last call announces the first batches of the next run (an input pipeline that knows what comes next) and
         all runs of the same n are identical -- the rehearsals below capture exactly the graphs the timed run replays."""
-        seq = lambda i: [batches[(i + j) % n_batches] for j in range(min(Cy, n - i))]
+        seq = lambda i: [batches[(i + j) % len(batches)] for j in range(min(Cy, n - i))]
         out, i = [], 0
         while i < n:
             cur = seq(i)
@@ -248,7 +396,7 @@ def main():
             for cur, nxt in calls_of(n):
                 step.many(cur, then=nxt)
             return
-        if sharded_mode and args.sharded_graph:
+        if sharded_mode and not args.sharded_eager:
             while n - i >= Cy:
                 b0 = i % n_batches
                 step.many(batches[b0:b0 + Cy])
@@ -278,6 +426,17 @@ def main():
     run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    # further regions of the same K steps (same graphs, same batches): the distribution behind the one reported number
+    rep_ms = []
+    for _ in range(max(0, args.repeats)):
+        barrier()
+        t1 = time.perf_counter()
+        run_steps(args.steps)
+        barrier()
+        e1 = time.perf_counter() - t1
+        if world > 1:
+            e1 = reduce_max(e1)
+        rep_ms.append(e1 / args.steps * 1e3)
     gc.enable()
     if world > 1:
         elapsed = reduce_max(elapsed)
@@ -328,9 +487,10 @@ def main():
     import ctypes as C
     from explicit_tf2_recommendation_amd._lib import lib, check
     vp = lambda t: C.c_void_p(t.data_ptr())
-    pmc = {}
+    pmc, pmc_file = {}, {}
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["kernels"]
+        pmc_file = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+        pmc = pmc_file["kernels"]
     except (OSError, ValueError, KeyError):
         pass
 
@@ -354,6 +514,9 @@ def main():
         tr = [pmc[k]["hbm_bytes_per_launch_corrected"] for k in traffic_keys if k in pmc]
         return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": sum(tr) if len(tr) == len(traffic_keys) else None,
+                "traffic_source": {"file": "profiles/r03_pmc_traffic.json", "commit": pmc_file.get("commit"),
+                                   "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                           "FETCH_SIZE doubled (gfx950); not re-measured in this run"},
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": us, "note": note}
 
     # (1) standalone gather + FM forward (what FMRankingLayer's forward launches): ids + embed rows + w + logit
@@ -372,11 +535,12 @@ def main():
 
     roofline_gather = roof("emb_fm_fwd_vec_kernel<8,2,fused> (embedding gather + FM, fused 128-B rows)", gather_bytes,
                            timed(launch_gather, 100), ["emb_fm_fwd_vec_kernel"],
-                           "a random row read costs one 128-B line whatever the row size; measured WITHOUT cache "
-                           "reuse (scripts/exp/gather_bench3.hip: fresh ids every launch) the chip sustains ~31 G lines/s "
-                           "= 3.9 TB/s, so the ceiling of this kernel is ~0.29 of the 8 TB/s spec in algorithmic bytes; "
-                           "every timed launch here takes another resident batch (no reuse through L2 / the 256-MB "
-                           "memory-side cache)")
+                           "a random row read costs one 128-B line whatever the row size (76 algorithmic bytes per lookup "
+                           "ride in 128 fetched).  At B = 8192 a launch is 213 k lookups: the bandwidth-delay regime -- the "
+                           "bare line read of the same ids (scripts/exp/gather_sweep.hip) takes 6.8 us, ~3.4 us of it launch "
+                           "ramp + two dependent HBM latencies; `sweep` shows the same kernel at larger batches, where the "
+                           "chip sustains ~48-50 G random lines/s (6.1-6.4 TB/s of lines).  Every timed launch takes another "
+                           "resident batch (no reuse through L2 / the 256-MB memory-side cache)")
     roofline_gather["physical_frac"] = (roofline_gather["traffic"] / (roofline_gather["avg_launch_us"] * 1e-6) / 1e9 /
                                         HBM_PEAK_GBS) if roofline_gather["traffic"] else None
 
@@ -433,15 +597,56 @@ def main():
             for i in range(n):
                 fs._launch_main(colss[i % n_batches], batches[i % n_batches]["label"], st, i % n_batches)
 
-        roofline = roof("deepfm_fwd_bwd_kernel<direct> (gather, FM, MLP on fp32 MFMA, BCE, backward, IndexedSlices values "
+        roofline = roof("deepfm3_kernel<direct, K0 in LDS> (gather, FM, MLP on fp32 MFMA, BCE, backward, IndexedSlices values "
                         "written to their de-duplicated slots; its workgroup partials are reduced in the next launch)",
-                        fused_bytes, timed(launch_fused, 48), ["deepfm_fwd_bwd_kernel"],
-                        "one 8-wave workgroup (32 examples) per CU: a dependent chain ids -> rows (random 128-B lines, "
-                        "~31 G lines/s chip-wide) -> head -> backward with nothing to overlap it at 32 examples per CU; "
-                        "0.65 GFLOP of fp32 MFMA per launch is ~1% of the matrix peak, so HBM is the binding roofline")
+                        fused_bytes, timed(launch_fused, 48), ["deepfm3_kernel"],
+                        "one 8-wave workgroup (32 examples) per CU = two 16-example halves one phase apart: the backward of "
+                        "half A runs on the matrix cores while the rows of half B are still landing.  What bounds a launch at "
+                        "B = 8192 (phase stamps, profiles/r03_fused3_stamps.txt): launch ramp + ids (2 us) + the CU's 832 rows "
+                        "at ~25 GB/s per CU (to 8.6 us) + 4.2 us of fp32 MFMA per CU (0.65 GFLOP at the f32 rate) + two head "
+                        "latencies, then ~3 us for 27 MB of writes to leave the chip")
 
     extra = {}
-    if args.adam_steps > 0 and rank == 0:
+    if rep_ms:
+        r_ = np.array(rep_ms)
+        extra["stats"] = {"regions": len(rep_ms), "steps_per_region": args.steps,
+                          "ms_per_step_median": float(np.median(r_)), "ms_per_step_p10": float(np.percentile(r_, 10)),
+                          "ms_per_step_p90": float(np.percentile(r_, 90)), "ms_per_step_min": float(r_.min()),
+                          "value_median": world * B / (float(np.median(r_)) * 1e-3),
+                          "note": "further timed regions of the same K steps in this run (same graphs, same batches, barrier "
+                                  "+ synchronize on both sides each); `value` / `ms_per_step` are the FIRST region"}
+    if not args.no_extras and not sharded_mode and not args.generic and world == 1:
+        # the same measurement on Zipf(1.05) ids: hot ids form long runs in the de-duplication
+        gz_ = data.SyntheticGenerator(names, V, dist="zipf", seed=rank)
+        zb = [data.to_device(gz_.batch(B)) for _ in range(n_batches)]
+        zstep = engine.DeepFMFusedStep(layer, B, gz_.dims, gz_.offsets, optimizer=None, use_graph=not args.no_graph)
+
+        def zrun(n):
+            for cur, nxt in calls_of(n, zb):
+                zstep.many(cur, then=nxt)
+
+        zrun(2 * n_batches)
+        for _ in range(4):
+            zrun(args.steps)
+        zt = []
+        for _ in range(5):
+            barrier()
+            t1 = time.perf_counter()
+            zrun(args.steps)
+            barrier()
+            zt.append((time.perf_counter() - t1) / args.steps)
+        zstep.check_flags()
+        extra["value_zipf"] = world * B / float(np.median(zt))
+        extra["ms_per_step_zipf"] = float(np.median(zt)) * 1e3
+        del zb, zstep
+        roofline_gather["sweep"] = gather_sweep(lib, check, layer, V, F, E, names, timed)
+        extra["roofline_crossnet"] = crossnet_record(ops, timed)
+    if not args.no_extras and not args.no_dssm:
+        try:
+            extra["scaling_dssm_d"] = dssm_record(world, rank, local_rank, barrier, reduce_max)
+        except Exception as e:                               # a secondary record never takes the headline line down
+            extra["scaling_dssm_d"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if args.adam_steps > 0 and rank == 0 and not args.no_extras:
         st2 = (engine.DeepFMTrainStep(layer, B, optimizer="keras_adam", lr=1e-3, use_graph=False) if args.generic else
                engine.DeepFMFusedStep(layer, B, gen.dims, gen.offsets, optimizer="keras_adam", lr=1e-3, use_graph=False))
         for i in range(2):
@@ -515,7 +720,7 @@ def main():
                           ("1 process per GPU, independent full-table replicas" if world > 1 else "single GPU"),
                           "global_batch": world * B,
                           "hipgraph": ("one graph per %d steps incl. the RCCL collectives" % Cy
-                                       if args.sharded_graph else False) if sharded_mode else
+                                       if not args.sharded_eager else False) if sharded_mode else
                           (not args.no_graph) and
                           ("one graph per %d steps, %d resident batches" % (Cy, n_batches) if cycle else "one per step"),
                           "step": "sharded, de-duplicate first, fixed-capacity exchanges (constant split sizes, nothing read "
