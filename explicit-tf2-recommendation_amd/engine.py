@@ -285,7 +285,7 @@ class DeepFMFusedStep:
     MAX_GRAPHS = 64     # captured hipGraphs kept (least recently used beyond that are dropped with the inputs they hold)
 
     def __init__(self, layer, batch_size, field_dims, field_offsets, optimizer=None, lr=1e-3, use_graph=True,
-                 direct=True, kernel=None):
+                 direct=True, kernel=None, want_prob=False):
         self.layer = layer
         self.direct = bool(direct)
         self.B = B = int(batch_size)
@@ -317,7 +317,13 @@ class DeepFMFusedStep:
         self.col_lo = torch.tensor([int(o) for o in field_offsets], dtype=torch.int64, device=dev)
         self.gz = torch.empty(B, **f32)
         self.vals = torch.empty((n, 16), **f32)
-        self.loss = torch.empty(1, **f32)
+        # per-step results of a many() call (a caller that keeps metrics reads them after the call): loss_steps[i] and --
+        # want_prob -- prob_steps[i] of the i-th batch; `loss` / `prob` are views of the LAST step's entries
+        self.loss_steps = torch.zeros(self.NBUF // 2, **f32)
+        self.prob_steps = torch.empty((self.NBUF // 2, B), **f32) if want_prob else None
+        self.loss = self.loss_steps[:1]
+        self.prob = self.prob_steps[0] if want_prob else None
+        self._row = 0                                                # row of the step being enqueued
         self.oob = torch.zeros(1, dtype=torch.int32, device=dev)
         self.bad_ids = torch.zeros(1, dtype=torch.int32, device=dev)
         self.g = {
@@ -439,6 +445,12 @@ class DeepFMFusedStep:
                                             _p(pl["dloc"]), _p(self.bad_ids), _p(self.sort_ws),
                                             C.c_void_p(stream.cuda_stream)), "rec_colsort_plan_dest_i64")
 
+    def _ploss(self):
+        return C.c_void_p(self.loss_steps.data_ptr() + 4 * self._row)
+
+    def _pprob(self):
+        return C.c_void_p(self.prob_steps.data_ptr() + 4 * self.B * self._row) if self.prob_steps is not None else None
+
     def _launch_main(self, cols, label, st, buf):
         """The fused kernel.  Direct mode: the plan in buffer ``buf`` is complete, so the value row of every run's first
         member goes straight to its slot of g_embed_rows (with gz and the id)."""
@@ -460,13 +472,13 @@ class DeepFMFusedStep:
                 check(lib.rec_deepfm_fused3_main_f32(
                     _p(emb), emb.stride(0), self.V, arr, F, self.B, _p(L.bias), _p(L.MLP_layer1.kernel_0), _p(self._k0t),
                     _p(L.MLP_layer1.bias_0), _p(L.MLP_layer1.kernel_1), _p(L.MLP_layer1.bias_1),
-                    _p(L.MLP_layer2.kernel_0), _p(L.MLP_layer2.bias_0), _p(label), _p(self.gz), _p(self.vals), None,
-                    _p(self.oob), _p(self.ws), st), "rec_deepfm_fused3_main_f32")
+                    _p(L.MLP_layer2.kernel_0), _p(L.MLP_layer2.bias_0), _p(label), _p(self.gz), _p(self.vals),
+                    self._pprob(), _p(self.oob), _p(self.ws), st), "rec_deepfm_fused3_main_f32")
                 return
             check(lib.rec_deepfm_fused3_main_direct_f32(
                 _p(emb), emb.stride(0), self.V, arr, F, self.B, _p(L.bias), _p(L.MLP_layer1.kernel_0), _p(self._k0t),
                 _p(L.MLP_layer1.bias_0), _p(L.MLP_layer1.kernel_1), _p(L.MLP_layer1.bias_1), _p(L.MLP_layer2.kernel_0),
-                _p(L.MLP_layer2.bias_0), _p(label), _p(self.gz), _p(self.vals), None, _p(self.oob), _p(self.ws),
+                _p(L.MLP_layer2.bias_0), _p(label), _p(self.gz), _p(self.vals), self._pprob(), _p(self.oob), _p(self.ws),
                 _p(pl["dloc"]), _p(pl["col_nu"]), _p(self.g_embed_rows), st), "rec_deepfm_fused3_main_direct_f32")
             return
         if not self.direct:
@@ -501,7 +513,7 @@ class DeepFMFusedStep:
             check(lib.rec_deepfm_fused_post_direct_adam_dev_f32(
                 self.F, self.B, _p(self.gz), _p(self.vals), _p(g["MLP_layer1.kernel_0"]), _p(g["MLP_layer1.bias_0"]),
                 _p(g["MLP_layer1.kernel_1"]), _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]),
-                _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(self.loss), _p(self.ws), _p(pl["perm"]),
+                _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), self._ploss(), _p(self.ws), _p(pl["perm"]),
                 _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.uniq_ids), _p(self.g_embed_rows),
                 _p(self.g_w_rows), _p(self.n_uniq), _p(pe), pe.stride(0), self.V, _p(me), _p(ve), _p(mw), _p(vw),
                 me.stride(0), mw.stride(0), _p(self._lr_t_dev), 0.9, 0.999, 1e-7,
@@ -512,14 +524,14 @@ class DeepFMFusedStep:
             check(lib.rec_deepfm_fused_post_f32(
                 self.F, self.B, _p(self.gz), _p(self.vals), _p(g["MLP_layer1.kernel_0"]), _p(g["MLP_layer1.bias_0"]),
                 _p(g["MLP_layer1.kernel_1"]), _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]),
-                _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(self.loss), _p(self.ws), _p(pl["perm"]),
+                _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), self._ploss(), _p(self.ws), _p(pl["perm"]),
                 _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.uniq_ids), _p(self.g_embed_rows),
                 _p(self.g_w_rows), _p(self.n_uniq), 0, st), "rec_deepfm_fused_post_f32")
             return
         check(lib.rec_deepfm_fused_post_direct_f32(
             self.F, self.B, _p(self.gz), _p(self.vals), _p(g["MLP_layer1.kernel_0"]), _p(g["MLP_layer1.bias_0"]),
             _p(g["MLP_layer1.kernel_1"]), _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]),
-            _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), _p(self.loss), _p(self.ws), _p(pl["perm"]), _p(pl["col_uid"]),
+            _p(g["MLP_layer2.bias_0"]), _p(g["bias"]), self._ploss(), _p(self.ws), _p(pl["perm"]), _p(pl["col_uid"]),
             _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.uniq_ids), _p(self.g_embed_rows), _p(self.g_w_rows),
             _p(self.n_uniq), st), "rec_deepfm_fused_post_direct_f32")
 
@@ -652,12 +664,14 @@ class DeepFMFusedStep:
             if then_cols:
                 start_ev = torch.cuda.Event()
                 start_ev.record(main)                            # a sort only needs ids: nothing of this call
+            self._row = 0
             self._launch_main(seq[0][0], seq[0][1], st, bufs[0])  # the critical path's first kernel goes first
             if then_cols:
                 side.wait_event(start_ev)
                 for j in range(0, len(then_cols), self.GROUP):   # GROUP batches (consecutive buffers) per sort call
                     self._sort_group(then_cols[j:j + self.GROUP], then_bufs[j], side)
             for i in range(n):
+                self._row = i
                 if i > 0:
                     self._launch_main(seq[i][0], seq[i][1], st, bufs[i])
                 t = t_base + i + 1                               # 1-based step (host scalar of the non-graphed optimizers)
@@ -699,6 +713,9 @@ class DeepFMFusedStep:
                 while len(self._graphs) > self.MAX_GRAPHS:
                     self._graphs.popitem(last=False)             # least recently used: graph and retained inputs go
         self.t = t_base + n
+        self.loss = self.loss_steps[n - 1:n]                     # the last step's
+        if self.prob_steps is not None:
+            self.prob = self.prob_steps[n - 1]
         self._prefetched = dict(zip(then_keys, then_bufs))
         self._half = 1 - cur_half if then_cols else cur_half
         return self.loss
@@ -1127,11 +1144,13 @@ class GraphedTrainStep:
     read cannot be captured.  Out-of-range ids then read as zero rows, as the kernels guarantee (no fault).
     """
 
-    def __init__(self, layer, example_batch, label_name="label", loss_fn=None, warmup=3):
+    def __init__(self, layer, example_batch, label_name="label", loss_fn=None, warmup=3, extra_loss_fn=None):
         from . import functional as Fn
         from . import layers as CL
         self.layer = layer
         self.label_name = label_name
+        self.extra_loss_fn = extra_loss_fn                   # (inputs dict) -> scalar added to the loss (DIN's L2 term)
+        self.out = None                                      # the layer's output of the last replay (graph pool tensor)
         self.static = {k: v.clone() for k, v in example_batch.items() if isinstance(v, torch.Tensor)}
         self.loss_fn = loss_fn or (lambda out, y: Fn.KerasBCE.apply(out, y))
         for m in layer.modules():
@@ -1165,7 +1184,10 @@ class GraphedTrainStep:
         ins = {k: v for k, v in self.static.items() if k != self.label_name}
         out = self.layer(ins)["output"]
         loss = self.loss_fn(out, self._target(out))
+        if self.extra_loss_fn is not None:
+            loss = loss + self.extra_loss_fn(ins)
         loss.backward()
+        self.out = out.detach()
         return loss.detach()
 
     def __call__(self, batch):

@@ -67,15 +67,15 @@ def auc_score(labels, scores):
     if n_pos == 0 or n_neg == 0:
         return float("nan")
     order = np.argsort(scores, kind="stable")
-    ranks = np.empty(len(scores), np.float64)
     s_sorted = scores[order]
-    i = 0
-    while i < len(scores):                       # average ranks over ties
-        j = i
-        while j + 1 < len(scores) and s_sorted[j + 1] == s_sorted[i]:
-            j += 1
-        ranks[order[i:j + 1]] = 0.5 * (i + j) + 1.0
-        i = j + 1
+    n = len(scores)
+    change = np.ones(n, bool)                      # first element of every group of tied scores
+    change[1:] = s_sorted[1:] != s_sorted[:-1]
+    starts = np.nonzero(change)[0]
+    ends = np.append(starts[1:], n)
+    avg = 0.5 * (starts + ends - 1) + 1.0          # average rank of a tie group (1-based)
+    ranks = np.empty(n, np.float64)
+    ranks[order] = avg[np.cumsum(change) - 1]
     return float((ranks[pos].sum() - n_pos * (n_pos + 1) / 2.0) / (n_pos * n_neg))
 
 
@@ -83,7 +83,18 @@ class ModelManager:
     def __init__(self, feature_names=["user_tag1", "user_tag2", "item_tag1", "item_tag2", "item_tag3"],
                  json_path=None, data_info=None, embedding_dims=16, lr=0.00003, label_name="label", batch=100,
                  epochs=30, layer="fm_ranking", model_params={}, continuous_features=None,
-                 behavior_series_features=None, adam_sparse_mode="keras", device="cuda", regularization_factor=0.01):
+                 behavior_series_features=None, adam_sparse_mode="keras", device="cuda", regularization_factor=0.01,
+                 engine="auto", staging_slots=2, steps_per_call=8):
+        # engine: 'auto' -- the train loop of a batch shape is compiled once: engine.DeepFMFusedStep for 'deepfm_ranking'
+        # with the reference's default head (two launches per iteration, optimizer inside, steps replayed from hipGraphs),
+        # engine.GraphedTrainStep (forward + loss + autograd backward as ONE replayed hipGraph) for every other layer;
+        # 'eager' -- every iteration through the autograd path, launch by launch (what rounds 1-2 did).
+        if engine not in ("auto", "eager"):
+            raise ValueError("engine must be 'auto' or 'eager'")
+        self.engine = engine
+        self.staging_slots = max(2, int(staging_slots))
+        self.steps_per_call = max(1, int(steps_per_call))    # train_step: iterations per hipGraph of the compiled DeepFM loop
+        self._eng = None                                     # built at the first train_loop call (needs the batch shapes)
         self.embedding_dims = embedding_dims
         self.lr = lr
         self.label_name = label_name
@@ -174,25 +185,71 @@ class ModelManager:
     def init_opt(self):
         self.opt = KerasAdam(self.model.trainable_variables, learning_rate=self.lr, sparse_mode=self.adam_sparse_mode)
 
+    # ---- metrics: tf.keras.metrics.AUC(name="auc") + Mean loss (2.FM/ModelManager.py:106-108) ---------------------------
+    # Keras' AUC is a STREAMING approximation: 200 thresholds ((i+1)/199 for i < 198, framed by -1e-7 and 1+1e-7), per
+    # threshold the counts of true / false positives `prediction > threshold`, ROC area by the trapezoid rule
+    # (summation_method='interpolation').  Restated as a histogram: a prediction falls into bucket k = number of thresholds
+    # below it; TP[i] = positives in buckets > i.  Two tiny device kernels per iteration, nothing read back until the
+    # result is asked for (the reference logs every 500 steps, 2.FM/ModelManager.py:194-199; a per-step .item() would
+    # stall the GPU once per iteration, and an exact rank-AUC of an epoch sorts millions of scores on the host).
+    AUC_THRESHOLDS = 200
+
     def init_metric(self):
-        self._loss_sum, self._loss_n, self._y, self._p = 0.0, 0, [], []
+        self._loss_sum, self._loss_n = 0.0, 0
+        self._auc_hist = np.zeros((2, self.AUC_THRESHOLDS + 1), np.float64)      # [negatives | positives] per bucket (host)
+        self._dev_metric = None                                                 # device accumulators of the compiled loop
 
     def _metric_reset(self):
         self.init_metric()
 
+    @classmethod
+    def _auc_thresholds(cls):
+        n = cls.AUC_THRESHOLDS
+        return np.array([-1e-7] + [(i + 1) / (n - 1) for i in range(n - 2)] + [1.0 + 1e-7], np.float64)
+
+    def _metric_update_dev(self, loss, target, prob, n_steps=1):
+        d = self._dev_metric
+        if d is None:
+            dev = loss.device
+            d = self._dev_metric = {"thr": torch.from_numpy(self._auc_thresholds().astype(np.float32)).to(dev),
+                                    "hist": torch.zeros(2 * (self.AUC_THRESHOLDS + 1), dtype=torch.float32, device=dev),
+                                    "loss": torch.zeros(1, dtype=torch.float64, device=dev), "n": 0}
+        y = target.reshape(-1)
+        k = torch.bucketize(prob.reshape(-1).contiguous(), d["thr"], right=False)       # thresholds strictly below p
+        d["hist"].index_add_(0, k + (y > 0.5).to(torch.int64) * (self.AUC_THRESHOLDS + 1), torch.ones_like(y))
+        d["loss"] += loss.reshape(-1)[:n_steps].to(torch.float64).sum()
+        d["n"] += n_steps
+
     def _metric_update(self, loss, target, output):
         self._loss_sum += float(loss)
         self._loss_n += 1
-        self._y.append(target.detach().reshape(target.shape[0], -1)[:, 0].cpu().numpy())
+        y = target.detach().reshape(target.shape[0], -1)[:, 0].cpu().numpy()
         out = output.detach()
         out = out[:, -1] if (out.dim() == 2 and out.shape[1] > 1) else out.reshape(-1)
-        self._p.append(out.cpu().numpy())
+        p = out.cpu().numpy().astype(np.float32)
+        k = np.searchsorted(self._auc_thresholds().astype(np.float32), p, side="left")
+        np.add.at(self._auc_hist, ((y > 0.5).astype(np.int64), k), 1.0)
 
     def _metric_result(self):
-        if not self._y:
+        d = self._dev_metric
+        if d is not None and d["n"] > 0:                     # ONE device -> host read
+            self._auc_hist += d["hist"].cpu().numpy().astype(np.float64).reshape(2, -1)
+            self._loss_sum += float(d["loss"].item())
+            self._loss_n += d["n"]
+            d["hist"].zero_(); d["loss"].zero_(); d["n"] = 0
+        if self._loss_n == 0:
             return {"auc": float("nan"), "loss": float("nan")}
-        return {"auc": auc_score(np.concatenate(self._y), np.concatenate(self._p)),
-                "loss": self._loss_sum / max(1, self._loss_n)}
+        neg, pos = self._auc_hist
+        # counts above threshold i = buckets i+1 ..: reverse cumulative sums
+        tp = np.cumsum(pos[::-1])[::-1][1:]
+        fp = np.cumsum(neg[::-1])[::-1][1:]
+        n_pos, n_neg = pos.sum(), neg.sum()
+        if n_pos == 0 or n_neg == 0:
+            auc = float("nan")
+        else:
+            tpr, fpr = tp / n_pos, fp / n_neg
+            auc = float(np.sum((fpr[:-1] - fpr[1:]) * (tpr[:-1] + tpr[1:]) / 2.0))
+        return {"auc": auc, "loss": self._loss_sum / max(1, self._loss_n)}
 
     def _to_device(self, inputs):
         out = {}
@@ -210,9 +267,120 @@ class ModelManager:
         all_ids = torch.cat([p.to(torch.int64) for p in parts])
         return Fn.UsedRowsL2.apply(lay.embed.embeddings, all_ids, self.regularization_factor)
 
-    def train_loop(self, inputs):
+    # ---- the compiled train loop -------------------------------------------------------------------------------
+    def _fill(self, slot, inputs):
+        """Copy a batch into a staging slot (dict of device tensors of fixed shape; None: allocate one)."""
+        src = {}
+        for name, v in inputs.items():
+            t = v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))
+            if t.dtype in (torch.float64, torch.float16, torch.bfloat16):
+                t = t.to(torch.float32)                      # labels / continuous features: float32 (2.FM/ModelManager.py:92)
+            elif t.dtype in (torch.int32, torch.int16, torch.int8, torch.uint8):
+                t = t.to(torch.int64)
+            src[name] = t
+        if slot is None:
+            # tensors of one (dtype, shape) -- the 26 id columns of a DeepFM batch -- live in ONE block, so that a batch is
+            # staged by one stack / one host-to-device copy per group instead of one copy per feature (27 launches, ~0.1 ms
+            # of host time per batch)
+            groups = {}
+            for n, t in src.items():
+                groups.setdefault((t.dtype, tuple(t.shape)), []).append(n)
+            slot = {"__groups__": []}
+            for (dt, shp), members in groups.items():
+                block = torch.empty((len(members),) + shp, dtype=dt, device=self.device)
+                slot["__groups__"].append((members, block))
+                for g, n in enumerate(members):
+                    slot[n] = block[g]
+        for n, t in src.items():
+            if n not in slot or tuple(slot[n].shape) != tuple(t.shape) or slot[n].dtype != t.dtype:
+                raise ValueError("the compiled train loop takes batches of one shape (%r changed): build another "
+                                 "ModelManager, or engine='eager'" % n)
+        for members, block in slot["__groups__"]:
+            srcs = [src[n] for n in members]
+            if all(t.is_cuda for t in srcs):
+                if len(srcs) == 1:
+                    block[0].copy_(srcs[0])
+                else:
+                    torch.stack(srcs, out=block)             # one launch
+            elif not any(t.is_cuda for t in srcs):
+                block.copy_(torch.stack(srcs) if len(srcs) > 1 else srcs[0].unsqueeze(0), non_blocking=True)   # one copy
+            else:
+                for g, t in enumerate(srcs):
+                    block[g].copy_(t, non_blocking=True)
+        return slot
+
+    def _stage(self, inputs):
+        """Copy a batch into the next slot of a fixed ring of device staging buffers: the compiled step sees the same
+        addresses again and again, so its hipGraphs are captured once per slot and replayed -- whatever the input
+        pipeline hands over (host arrays, fresh device tensors)."""
+        ring = self.__dict__.setdefault("_ring", [])
+        k = self.__dict__.get("_ring_pos", 0)
+        self._ring_pos = (k + 1) % self.staging_slots
+        if len(ring) <= k:
+            ring.append(None)
+        ring[k] = self._fill(ring[k], inputs)
+        return ring[k]
+
+    def _build_engine(self, slot):
+        from . import engine as EN
+        lay = self.model
+        info = self.feature_info
+        B = slot[self.label_name].numel()
+        fused_ok = (isinstance(lay, CL.DeepFMRankingLayer) and lay.embedding_dims == 16 and
+                    list(lay.mlp_dims) == [32, 8] and len(lay.feature_names) <= 28 and B <= 16384 and
+                    isinstance(info, (list, tuple)) and len(info) >= 2 and
+                    len(info[0]) == len(lay.feature_names) == len(info[1]) and str(self.device).startswith("cuda"))
+        if fused_ok:
+            try:
+                opt = "keras_adam_lazy" if self.adam_sparse_mode == "keras" else "lazy_adam"
+                step = EN.DeepFMFusedStep(lay, B, list(info[0]), list(info[1]), optimizer=opt, lr=self.lr, want_prob=True)
+                return ("fused", step)
+            except NotImplementedError:
+                pass
+        extra = None
+        if isinstance(lay, CL.DINLayer) and self.regularization_factor and hasattr(lay.embed, "embeddings"):
+            extra = lambda ins: self.used_rows_l2(ins)
+        step = EN.GraphedTrainStep(lay, slot, label_name=self.label_name,
+                                   loss_fn=lambda out, y: Fn.KerasBCE.apply(out, y), extra_loss_fn=extra)
+        return ("graphed", step)
+
+    def sync_parameters(self):
+        """Bring every parameter up to date before it is read from outside the train loop (evaluation, export): the
+        compiled DeepFM step evaluates Keras' dense Adam sweep LAZILY -- rows skip the sweeps and replay them when a
+        batch reads them -- and this replays what is still pending for every row (bit-identical to sweeping each step)."""
+        if self._eng is not None and self._eng[0] == "fused":
+            self._eng[1].flush()
+
+    def train_loop(self, inputs, next_inputs=None):
         """One iteration of 2.FM/ModelManager.py:171-181 (DIN: 5.DIN/ModelManager.py:170-197, which adds the L2 term
-        on the embedding rows the batch used)."""
+        on the embedding rows the batch used).  Returns the loss as a DEVICE scalar (no synchronisation).
+        ``next_inputs``: the batch of the next call, if the caller already has it -- its de-duplication plan is then built
+        beside this iteration (compiled DeepFM step)."""
+        if self.engine == "auto" and str(self.device).startswith("cuda"):
+            pend = self.__dict__.get("_pending")
+            if pend is not None and pend[0] is inputs:       # staged (and its plan prefetched) by the previous call
+                slot = pend[1]
+            else:
+                slot = self._stage(inputs)
+            self._pending = None
+            if self._eng is None:
+                self._eng = self._build_engine(slot)
+            kind, step = self._eng
+            target = slot[self.label_name]
+            if kind == "fused":
+                nxt = None
+                if next_inputs is not None:
+                    nxt = self._stage(next_inputs)
+                    self._pending = (next_inputs, nxt)       # the next call finds its batch staged (same dict object)
+                loss = step(slot, self.label_name, next_inputs=nxt).clone()   # the step's buffer is overwritten by the next call
+                self._metric_update_dev(loss, target, step.prob)
+                return loss
+            loss = step(slot).clone()
+            self.opt.apply_gradients()
+            out = step.out
+            prob = out[:, -1] if (out.dim() == 2 and out.shape[1] > 1) else out.reshape(-1)
+            self._metric_update_dev(loss, target, prob)
+            return loss
         inputs = self._to_device(inputs)
         target = inputs.pop(self.label_name)
         logits = self.model(inputs)
@@ -232,16 +400,50 @@ class ModelManager:
         self.set_feature_names(feature_names, label_name)
         return tfrecord.TFRecordDataset(data_dir, mode, self.feature_names, self.label_name, self.batch)
 
+    def _train_chunks(self, order):
+        """The epoch of the compiled DeepFM loop, `steps_per_call` iterations per call: a hipGraph launch leaves the GPU
+        idle for ~30 us and every call costs ~0.1 ms of Python, so the chunk of batches is staged into one half of a ring
+        of 2 x steps_per_call buffers, the next chunk into the other half (its de-duplication plans are built beside this
+        chunk's iterations), and the chunk runs as ONE replayed graph; the per-iteration losses / predictions come out of
+        the step's own per-step buffers, for the metrics."""
+        R = self.steps_per_call
+        step = self._eng[1]
+        ring = self.__dict__.setdefault("_chunk_ring", [[None] * R, [None] * R])
+
+        def stage(chunk, half):
+            for j, b in enumerate(chunk):
+                ring[half][j] = self._fill(ring[half][j], b)
+            return ring[half][:len(chunk)]
+
+        chunks = [order[i:i + R] for i in range(0, len(order), R)]
+        cur = stage(chunks[0], 0)
+        for c, chunk in enumerate(chunks):
+            nxt = stage(chunks[c + 1], (c + 1) % 2) if c + 1 < len(chunks) else None
+            step.many(cur, self.label_name, then=nxt)
+            n = len(cur)
+            y = torch.cat([s_[self.label_name].reshape(-1) for s_ in cur])
+            self._metric_update_dev(step.loss_steps[:n], y, step.prob_steps[:n].reshape(-1), n)
+            cur = nxt
+        self._pending = None
+
     def train_step(self, ds, epoch=None, summary_writer=None):
         self._metric_reset()
-        step = 0
-        for batch_data in sorted(list(ds), key=lambda x: random.random()):   # batch-order shuffle only (:185)
-            self.train_loop(dict(batch_data))
-            step += 1
+        order = [dict(b) for b in sorted(list(ds), key=lambda x: random.random())]    # batch-order shuffle only (:185)
+        if self.engine == "auto" and str(self.device).startswith("cuda") and order:
+            if self._eng is None:
+                self.train_loop(order[0])                    # builds the engine for this batch shape (and trains on it)
+                order = order[1:]
+            if self._eng[0] == "fused" and order:
+                self._train_chunks(order)
+                return self._metric_result()
+        for i, batch_data in enumerate(order):
+            nxt = order[i + 1] if i + 1 < len(order) else None                # the input pipeline knows what comes next
+            self.train_loop(batch_data, next_inputs=nxt)
         return self._metric_result()
 
     @torch.no_grad()
     def eval_step(self, ds):
+        self.sync_parameters()
         self._metric_reset()
         for batch_data in ds:
             inputs = self._to_device(dict(batch_data))
