@@ -508,3 +508,85 @@ def test_dedup_plan_captured_and_replayed_bit_exact(R, n, V):
         got = out.cpu().numpy()
         assert np.abs(got[:nu] - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
         assert np.all(got[nu:] == 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# tables larger than 4 GiB (configs D: 100M x 64d = 25.6 GB, E: 50M x 32d = 6.4 GB): row addressing
+# ---------------------------------------------------------------------------------------------------------------
+def _hash_rows(ids, E):
+    """Row r of the synthetic big table: element c = ((r * 2654435761 + c * 40503 + 12345) mod 1000003) / 1000003 - 0.5,
+    exactly representable steps in fp32 arithmetic done in int64 first (the same bits wherever it is evaluated)."""
+    r = ids.reshape(-1, 1).to(torch.int64)
+    c = torch.arange(E, device=ids.device, dtype=torch.int64).reshape(1, -1)
+    return (((r * 2654435761 + c * 40503 + 12345) % 1000003).to(torch.float32) / 1000003.0) - 0.5
+
+
+def _big_table(V, E, chunk=5_000_000):
+    tab = torch.empty((V, E), dtype=torch.float32, device="cuda")
+    for lo in range(0, V, chunk):
+        hi = min(V, lo + chunk)
+        tab[lo:hi] = _hash_rows(torch.arange(lo, hi, device="cuda"), E)
+    return tab
+
+
+@pytest.mark.parametrize("V,E", [(100_000_000, 64), (50_000_000, 32)])
+def test_gather_addresses_rows_beyond_4gib(R, V, E):
+    """rec_emb_gather_f32 on the tables of configs D (25.6 GB) and E (6.4 GB): every returned row is recomputed on the
+    device from its id (element = a hash of (row, column)) -- bit exact, including ids whose byte offset needs more than
+    32 bits, the last row, and ids drawn around the 4 GiB / 8 GiB / 16 GiB boundaries."""
+    tab = _big_table(V, E)
+    r = H.rng(V % 1000 + E)
+    ids = r.integers(0, V, size=200_000)
+    row_bytes = 4 * E
+    edges = []
+    for gib in (4, 8, 16, 24):
+        b = (gib << 30) // row_bytes
+        edges += [b - 2, b - 1, b, b + 1]
+    edges = np.array([e for e in edges if 0 <= e < V] + [0, V - 1], dtype=np.int64)
+    ids = np.concatenate([ids, edges])
+    assert (ids.astype(np.int64) * row_bytes).max() > (4 << 30)
+    idx = torch.from_numpy(ids).cuda()
+    got = R.ops.emb_gather(tab, idx)
+    assert torch.equal(got, _hash_rows(idx, E))
+    # the 2-D form the layers use ([B, F] ids -> [B, F, E]) and the strided form (a row stride larger than E)
+    X = idx[:199_998].reshape(-1, 3)
+    assert torch.equal(R.ops.emb_gather(tab, X), _hash_rows(X, E).reshape(X.shape[0], 3, E))
+    del tab, got
+    torch.cuda.empty_cache()
+
+
+def test_din_attention_addresses_rows_beyond_4gib(R):
+    """rec_din_attn_fwd_f32 / _bwd_f32 gather their keys inside the kernel: on the 50M x 32d table of config E (6.4 GB) the
+    scores, the pooled vectors and the key gradients must equal, bit for bit, those of the same call on a COMPACT table
+    that holds only the touched rows (ids remapped) -- i.e. every key was read from the right row of the big table."""
+    ops = R.ops
+    V, E, C, B, T_ = 50_000_000, 32, 3, 64, 100
+    D, Hh = C * E, 36
+    tab = _big_table(V, E)
+    r = H.rng(77)
+    series = r.integers(1, V, size=(B, T_, C))
+    series[:, :, 0] = np.where(r.random((B, T_)) < 0.3, 0, series[:, :, 0])      # padding positions (id 0)
+    series[0, 0] = [V - 1, (4 << 30) // (4 * E), (4 << 30) // (4 * E) + 1]       # the last row, the 4-GiB boundary
+    uniq, inv = np.unique(np.concatenate([[0], series.reshape(-1)]), return_inverse=True)
+    assert uniq[0] == 0
+    small = _hash_rows(torch.from_numpy(uniq).cuda(), E).contiguous()
+    ser_small = torch.from_numpy(inv[1:].reshape(B, T_, C).astype(np.int64)).cuda()
+    ser_big = torch.from_numpy(series.astype(np.int64)).cuda()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    Mext = torch.randn((B, D * Hh + Hh), device="cuda", generator=g) * 0.1
+    Wkd = torch.randn((D, Hh), device="cuda", generator=g) * 0.1
+    alpha = torch.rand(Hh, device="cuda", generator=g)
+    w2 = torch.randn(Hh, device="cuda", generator=g)
+    b2 = torch.zeros(1, device="cuda")
+    gp = torch.randn((B, D), device="cuda", generator=g)
+    kind = ops.DACT_CODE["prelu"]
+    for mask_valid in (0, 1):
+        outs = []
+        for table, ser in ((tab, ser_big), (small, ser_small)):
+            sc, po = ops.din_attn_fwd(table, ser, Mext, Wkd, kind, alpha, None, None, w2, b2, 0, mask_valid)
+            bw = ops.din_attn_bwd(table, ser, Mext, Wkd, kind, alpha, None, None, w2, b2, 0, mask_valid, sc, gp)
+            outs.append((sc, po) + tuple(bw))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+    del tab
+    torch.cuda.empty_cache()
