@@ -353,6 +353,7 @@ def main():
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         if rehearsal:
             from explicit_tf2_recommendation_amd import sharded as _sh
+            args.sharded_eager = True                    # exchanges through host memory cannot be captured in a hipGraph
             step = engine.ShardedDeepFMStep(layer, B, gen.dims, gen.offsets, comm=_sh.HostStagedComm(None, True))
         else:
             step = engine.ShardedDeepFMStep(layer, B, gen.dims, gen.offsets)

@@ -72,6 +72,7 @@ SIGNATURES = {
     "rec_colsort_shard_map_fixed_i64": (i32, [p, p, p, p, i64, i32, i64, i32, i64, p, p, p, p, p, p]),
     "rec_emb_gather_lists_f32": (i32, [p, i64, i32, i64, p, i32, i64, p, p, p]),
     "rec_shard_slab_map_i64": (i32, [p, p, p, p, i64, i64, i32, i64, p, p, p, p]),
+    "rec_shard_slab_map_uslot_i64": (i32, [p, p, p, p, i64, i64, i32, i64, p, p, p, p, p]),
     "rec_dedup_plan_sorted_slabs_i64": (i32, [p, i32, i64, i64, p, p, p, p, p, sz, p]),
     "rec_deepfm_fused_post_slots_f32": (i32, [i32, i64] + [p] * 17 + [p]),
     "rec_permute_rows_f32": (i32, [p, p, i64, i32, i32, p, p]),

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void shard_slab_map_kernel(const int64_t* __re
                                                              const int32_t* __restrict__ perm, int64_t n,
                                                              int64_t rows_per_shard, int n_shard, int64_t cap,
                                                              int64_t* __restrict__ msg, int64_t* __restrict__ slot,
-                                                             int* __restrict__ flag) {
+                                                             int64_t* __restrict__ uslot, int* __restrict__ flag) {
   __shared__ int64_t first_s[MAX_SHARD + 1];
   const int64_t nu = *n_uniq_p;
   if (threadIdx.x <= n_shard)                    // first unique index of every owner's slice (and the end)
@@ -398,6 +398,9 @@ __global__ __launch_bounds__(256) void shard_slab_map_kernel(const int64_t* __re
     if (o < 0 || o >= n_shard) { o = o < 0 ? 0 : n_shard - 1; if (flag) *flag = 1; }
     const int64_t r = t - first_s[o];
     if (r < cap) msg[(int64_t)o * (cap + 2) + 2 + r] = id - (int64_t)o * rows_per_shard;
+    if (uslot) uslot[t] = (int64_t)o * cap + (r < cap ? r : cap - 1);
+  } else if (t < n && uslot) {                   // padded tail: one row PAST the buffer (the caller's dump row)
+    uslot[t] = (int64_t)n_shard * cap;
   }
   if (t < n) {                                   // slot of the lookup behind sorted position t
     int64_t lo = 0, hi = nu;                     // largest j with seg_start[j] <= t
@@ -426,7 +429,22 @@ extern "C" int rec_shard_slab_map_i64(const int64_t* uniq_ids, const int64_t* n_
   if (!uniq_ids || !n_uniq || !seg_start || !perm || !msg || !slot) return REC_E_ARG;
   const int64_t threads = n > n_shard ? n : n_shard;
   hipLaunchKernelGGL(shard_slab_map_kernel, dim3((unsigned)ceil_div64(threads, 256)), dim3(256), 0, as_stream(stream),
-                     uniq_ids, n_uniq, seg_start, perm, n, rows_per_shard, n_shard, cap, msg, slot, oob_flag);
+                     uniq_ids, n_uniq, seg_start, perm, n, rows_per_shard, n_shard, cap, msg, slot, nullptr, oob_flag);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
+extern "C" int rec_shard_slab_map_uslot_i64(const int64_t* uniq_ids, const int64_t* n_uniq, const int32_t* seg_start,
+                                            const int32_t* perm, int64_t n, int64_t rows_per_shard, int n_shard,
+                                            int64_t cap, int64_t* msg, int64_t* slot, int64_t* uslot, int* oob_flag,
+                                            void* stream) {
+  if (n < 0 || rows_per_shard <= 0 || n_shard <= 0 || cap <= 0) return REC_E_ARG;
+  if (n_shard > MAX_SHARD) return REC_E_UNSUPPORTED;
+  if (n == 0) return REC_OK;
+  if (!uniq_ids || !n_uniq || !seg_start || !perm || !msg || !slot || !uslot) return REC_E_ARG;
+  const int64_t threads = n > n_shard ? n : n_shard;
+  hipLaunchKernelGGL(shard_slab_map_kernel, dim3((unsigned)ceil_div64(threads, 256)), dim3(256), 0, as_stream(stream),
+                     uniq_ids, n_uniq, seg_start, perm, n, rows_per_shard, n_shard, cap, msg, slot, uslot, oob_flag);
   REC_LAUNCH_CHECK();
   return REC_OK;
 }

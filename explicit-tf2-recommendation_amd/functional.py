@@ -32,10 +32,17 @@ class GradSink:
     with its own values and builds ONE plan over both id lists.  Without it torch concatenates the two sparse gradients
     (a 157-MB copy at DIN config E) and each lookup sorts on its own."""
 
-    def __init__(self, n_head):
+    def __init__(self, n_head, n_tail=0):
         self.n_head = int(n_head)
+        self.n_tail = int(n_tail)                            # zero rows behind the series' values (sharded.ShardedEmbedding)
         self.ids = None
         self.buf = None
+
+    def new_buf(self, n_series, E, device):
+        buf = torch.empty((self.n_head + n_series + self.n_tail, E), dtype=torch.float32, device=device)
+        if self.n_tail:
+            buf[self.n_head + n_series:].zero_()
+        return buf
 
     def take(self):
         ids, buf = self.ids, self.buf
@@ -339,8 +346,8 @@ class DinAttention(torch.autograd.Function):
         sink, buf, dst = ctx.sink, None, None
         if sink is not None:                                 # values land behind the Gather's rows in one shared buffer
             n_ser = series.numel()
-            buf = torch.empty((sink.n_head + n_ser, E), dtype=torch.float32, device=embed.device)
-            dst = buf[sink.n_head:].view(series.shape[0], series.shape[1], D)
+            buf = sink.new_buf(n_ser, E, embed.device)
+            dst = buf[sink.n_head:sink.n_head + n_ser].view(series.shape[0], series.shape[1], D)
         gkeys, gMext, gw2p, galphap, gb2p = ops.din_attn_bwd(embed, series, Mext, Wkd, kind, alpha, mean, var, w2, b2,
                                                              padding_index, mask_valid, scores, gpooled.contiguous(),
                                                              gkeys=dst)
@@ -431,8 +438,8 @@ class IpAttention(torch.autograd.Function):
         V, E = embed.shape
         sink, dst = ctx.sink, None
         if sink is not None:
-            buf = torch.empty((sink.n_head + series.numel(), E), dtype=torch.float32, device=embed.device)
-            dst = buf[sink.n_head:].view(series.shape[0], series.shape[1], -1)
+            buf = sink.new_buf(series.numel(), E, embed.device)
+            dst = buf[sink.n_head:sink.n_head + series.numel()].view(series.shape[0], series.shape[1], -1)
         gkeys, gq = ops.ip_attn_bwd(embed, series, q, ctx.padding_index, scores, gpooled.contiguous(), gkeys=dst)
         if sink is not None:
             sink.ids, sink.buf = series, buf

@@ -733,8 +733,10 @@ class DINLayer(Layer):
             rows, slot = self.embed.exchange(torch.cat([X_cate.reshape(-1), series.reshape(-1), pad]), flag)
             s_cate = slot[:n1].reshape(X_cate.shape).contiguous()
             s_series = slot[n1:n1 + n2].reshape(series.shape).contiguous()
-            sink = self.embed.grad_sink(X_cate)
-            profile = Fn.Gather.apply(rows, s_cate, None, sink)
+            # (the consumers' gradients -- profile rows, series values, a zero row for the padding lookup -- line up with
+            # the exchange's id list, whose de-duplication plan the backward reuses)
+            sink = self.embed.grad_sink(X_cate, n_tail=1)
+            profile = self.embed.take(rows, s_cate, sink)
             profile_output = profile.reshape(profile.shape[0], -1)
             q = profile[:, profile.shape[1] - n_item:, :].reshape(profile.shape[0], -1)
             pooled, _ = self.din_activation_layer.attend(rows, q, s_series, 0, mask_valid, None, sink)

@@ -47,15 +47,18 @@ class HipBackend:
 
     @staticmethod
     def slab_map(plan, n, rows_per_shard, n_shard, cap, flag):
-        """msg [P, 2+cap] (count, 0, owner-local ids ascending) and slot [n] (row of every lookup in the [P*cap, E]
-        buffer the rows come back in): rec_shard_slab_map_i64."""
+        """msg [P, 2+cap] (count, 0, owner-local ids ascending), slot [n] (row of every lookup in the [P*cap, E] buffer the
+        rows come back in) and uslot [n] (the same per UNIQUE id, in the plan's order; P*cap -- one row past the buffer --
+        beyond the last unique): rec_shard_slab_map_uslot_i64."""
         dev = plan.uniq_ids.device
         msg = torch.zeros((n_shard, cap + 2), dtype=torch.int64, device=dev)
         slot = torch.empty(n, dtype=torch.int64, device=dev)
-        ops.check(ops.lib.rec_shard_slab_map_i64(ops._ptr(plan.uniq_ids), ops._ptr(plan.n_uniq), ops._ptr(plan.seg_start),
-                                                 ops._ptr(plan.perm), n, rows_per_shard, n_shard, cap, ops._ptr(msg),
-                                                 ops._ptr(slot), ops._ptr(flag), ops._stream()), "rec_shard_slab_map_i64")
-        return msg, slot
+        uslot = torch.empty(n, dtype=torch.int64, device=dev)
+        ops.check(ops.lib.rec_shard_slab_map_uslot_i64(ops._ptr(plan.uniq_ids), ops._ptr(plan.n_uniq),
+                                                       ops._ptr(plan.seg_start), ops._ptr(plan.perm), n, rows_per_shard,
+                                                       n_shard, cap, ops._ptr(msg), ops._ptr(slot), ops._ptr(uslot),
+                                                       ops._ptr(flag), ops._stream()), "rec_shard_slab_map_uslot_i64")
+        return msg, slot, uslot
 
     @staticmethod
     def gather_lists(table, msg, n_shard, cap, flag):
@@ -67,9 +70,12 @@ class HipBackend:
         return out
 
     @staticmethod
-    def take_rows(rows, slots, sink):
-        """out[i] = rows[slots[i]] with a sparse (de-duplicated) gradient for `rows`: the ordinary gather of layers.py on
-        the local [P*cap, E] buffer."""
+    def take_rows(rows, slots, sink, xplan=None):
+        """out[i] = rows[slots[i]].  With the exchange's plan (``xplan``, covering exactly the lookups of `slots` followed by
+        those the sink collects) the gradient of `rows` is dense and costs ONE segment sum -- the forward's de-duplication
+        is reused; without it: the ordinary gather of layers.py (sparse gradient from a de-duplication of its own)."""
+        if xplan is not None:
+            return _TakeRows.apply(rows, slots, sink, xplan)
         from . import functional as Fn
         return Fn.Gather.apply(rows, slots, None, sink)
 
@@ -166,6 +172,47 @@ class HostStagedComm(DistComm):
         return x
 
 
+class _SlabPlan:
+    """What the forward's de-duplication leaves for the backward: the sorted-unique plan of the exchanged ids -- which is
+    also the plan of their slots (slot is monotone in the id) -- and the slot of every unique id."""
+    __slots__ = ("plan", "uslot", "n", "world", "cap")
+
+    def __init__(self, plan, uslot, n, world, cap):
+        self.plan, self.uslot, self.n, self.world, self.cap = plan, uslot, n, world, cap
+
+
+class _TakeRows(torch.autograd.Function):
+    """out[i] = rows[slots[i]] on the local [P*cap, E] buffer of an exchange; backward = segment sums of the consumers'
+    gradient in the order of the exchange's plan (no second sort), laid out dense by slot."""
+
+    @staticmethod
+    def forward(ctx, rows, slots, sink, xplan):
+        out = ops.emb_gather(rows, slots, None)
+        ctx.sink, ctx.xplan, ctx.n_rows = sink, xplan, rows.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xp, E = ctx.xplan, g.shape[-1]
+        g = g.contiguous().reshape(-1, E)
+        _ids, buf = ctx.sink.take() if ctx.sink is not None else (None, None)
+        if buf is not None:                                  # lookups of the same exchange that went elsewhere (DIN's
+            buf[: g.shape[0]].copy_(g)                       # series through the attention kernel) wrote behind the head
+        elif g.shape[0] == xp.n:
+            buf = g
+        else:                                                # lookups of the exchange nobody differentiated: zero rows
+            buf = torch.zeros((xp.n, E), dtype=torch.float32, device=g.device)
+            buf[: g.shape[0]].copy_(g)
+        if buf.shape[0] != xp.n:
+            raise ValueError("the exchange covered %d lookups, their gradients %d rows" % (xp.n, buf.shape[0]))
+        sums = xp.plan.segment_sum(buf, E)                   # [n, E] in the plan's order; rows >= n_uniq are zero
+        if xp.world == 1:
+            return sums[: xp.cap], None, None, None          # one owner: slot = rank of the unique id (cap <= n)
+        dense = torch.zeros((xp.world * xp.cap + 1, E), dtype=torch.float32, device=g.device)
+        dense.index_copy_(0, xp.uslot, sums)                 # unique slots; the padded tail lands on the extra row
+        return dense[: xp.world * xp.cap], None, None, None
+
+
 class _Exchange(torch.autograd.Function):
     """ids -> (rows [P*cap, E], slot [n]): de-duplicate first, then exchange in FIXED-CAPACITY slabs -- constant split
     sizes, so no count exchange, nothing read back by the host, every shape known before the call: the whole lookup (and
@@ -187,18 +234,20 @@ class _Exchange(torch.autograd.Function):
         n = ids.numel()
         cap = emb.capacity_for(n)
         plan = be.plan(ids, P * rps)
-        msg, slot = be.slab_map(plan, n, rps, P, cap, flag)
+        msg, slot, uslot = be.slab_map(plan, n, rps, P, cap, flag)
         msg_theirs = comm.exchange_ids(msg, torch.empty_like(msg)) if P > 1 else msg          # C1
         rows_out = be.gather_lists(shard, msg_theirs, P, cap, flag)
         rows = comm.exchange(rows_out, torch.empty_like(rows_out)) if P > 1 else rows_out     # C2
-        ctx.save_for_backward(msg_theirs)
+        emb._xplan = _SlabPlan(plan, uslot, n, P, cap)       # for the consumers' backward (ShardedEmbedding.take)
+        # one owner: the unique ids it was asked for ARE the plan's (ascending, tail = the first id, as DedupPlan pads)
+        ctx.save_for_backward(msg_theirs, plan.uniq_ids[:cap] if P == 1 else None)
         ctx.meta = (emb, cap, tuple(shard.shape))
         ctx.mark_non_differentiable(slot)
         return rows, slot
 
     @staticmethod
     def backward(ctx, g, _gslot):
-        (msg_theirs,) = ctx.saved_tensors
+        msg_theirs, uniq_own = ctx.saved_tensors
         emb, cap, shape = ctx.meta
         be, comm = emb.backend, emb.comm
         P = comm.world
@@ -215,6 +264,9 @@ class _Exchange(torch.autograd.Function):
             dense.index_add_(0, idx, vals)
             g = dense[: P * cap]
         g = g.contiguous()
+        if P == 1 and uniq_own is not None:
+            # one owner, one list: nothing to merge -- the rows are already the sums per unique id, in ascending id order
+            return torch.sparse_coo_tensor(uniq_own.unsqueeze(0), g, shape), None, None, None
         g_theirs = comm.exchange(g, torch.empty_like(g)) if P > 1 else g                       # C3
         uniq, rows, _ = be.owner_reduce(msg_theirs, g_theirs, P, cap, emb.rows_per_shard)
         return torch.sparse_coo_tensor(uniq[: rows.shape[0]].unsqueeze(0), rows, shape), None, None, None
@@ -253,6 +305,7 @@ class ShardedEmbedding(torch.nn.Module):
             shard = (torch.rand((self.rows_per_shard, embedding_dim), generator=g) * 2 - 1) * init_scale
         self.embeddings_shard = torch.nn.Parameter(shard)
         self.flag = None                                         # device int32: overflow / out-of-range, set by the kernels
+        self._xplan = None                                       # the last exchange's plan (take())
 
     def capacity_for(self, n):
         cap = min(int(n), self.rows_per_shard)
@@ -267,11 +320,18 @@ class ShardedEmbedding(torch.nn.Module):
             self.embeddings_shard.zero_()
             self.embeddings_shard[: hi - lo].copy_(table[lo:hi])
 
-    def grad_sink(self, X):
+    def grad_sink(self, X, n_tail=0):
+        """``n_tail``: lookups of the exchange BEHIND those the sink collects that nobody differentiates (DIN's padding
+        id): the shared gradient buffer gets as many zero rows, so that it lines up with the exchange's plan."""
         from . import functional as Fn
         if torch.is_grad_enabled() and self.embeddings_shard.requires_grad:
-            return Fn.GradSink(X.numel())
+            return Fn.GradSink(X.numel(), n_tail)
         return None
+
+    def take(self, rows, slots, sink=None):
+        """rows[slots] for the lookups at the HEAD of the last exchange's id list (the rest, if any, reach their consumers
+        through ``sink``): the gradient of the rows buffer comes out of the exchange's own plan."""
+        return self.backend.take_rows(rows, slots, sink, self._xplan)
 
     def exchange(self, ids, oob=None):
         """(rows [P*cap, E] -- differentiable --, slot [n]) for the flat id list: rows[slot[i]] = table[ids[i]].  For a
@@ -285,7 +345,7 @@ class ShardedEmbedding(torch.nn.Module):
 
     def forward(self, X, oob=None, sink=None):
         rows, slot = self.exchange(X, oob)
-        out = self.backend.take_rows(rows, slot.reshape(X.shape), sink)
+        out = self.take(rows, slot.reshape(X.shape), sink)
         return out.reshape(tuple(X.shape) + (self.embedding_dim,))
 
     def check_flags(self):

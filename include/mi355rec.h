@@ -250,6 +250,13 @@ int rec_colsort_shard_map_fixed_i64(const int32_t* perm, const int64_t* col_uid,
 int rec_shard_slab_map_i64(const int64_t* uniq_ids, const int64_t* n_uniq, const int32_t* seg_start, const int32_t* perm,
                            int64_t n, int64_t rows_per_shard, int n_shard, int64_t cap, int64_t* msg, int64_t* slot,
                            int* oob_flag, void* stream);
+/* The same, and uslot [n] int64: the slot of every UNIQUE id (rank u of the plan -> owner * cap + j; ranks >= *n_uniq ->
+ * n_shard * cap, one row past the buffer).  The plan of the ids is then also the plan of the slots (slot is monotone in the
+ * id), which is what lets the backward of the lookup reuse the forward's de-duplication: segment sums in the plan's order,
+ * scattered by uslot, are the dense gradient of the [n_shard * cap, E] rows buffer. */
+int rec_shard_slab_map_uslot_i64(const int64_t* uniq_ids, const int64_t* n_uniq, const int32_t* seg_start,
+                                 const int32_t* perm, int64_t n, int64_t rows_per_shard, int n_shard, int64_t cap,
+                                 int64_t* msg, int64_t* slot, int64_t* uslot, int* oob_flag, void* stream);
 /* Owner side of it.  Gather for n_lists received slabs (msg layout above): out [n_lists * cap, E], row (q, j) written
  * only for j < count_q = the first E floats of the table row (E a multiple of 4 up to 256, E <= ld; the sharded
  * DeepFM step sends E = 20 of the 32 floats of a fused row: [embed 16 | w | pad]); 16-byte aligned operands. */

@@ -90,7 +90,9 @@ class OracleBackend:
         slot = np.empty(n, np.int64)
         pos_to_u = np.searchsorted(seg, np.arange(n), side="right") - 1
         slot[plan.perm.numpy()] = uslot[pos_to_u]
-        return torch.from_numpy(msg), torch.from_numpy(slot)
+        us = np.full(n, n_shard * cap, np.int64)
+        us[:nu] = uslot
+        return torch.from_numpy(msg), torch.from_numpy(slot), torch.from_numpy(us)
 
     @staticmethod
     def gather_lists(table, msg, n_shard, cap, flag):
@@ -103,7 +105,7 @@ class OracleBackend:
         return torch.from_numpy(out)
 
     @staticmethod
-    def take_rows(rows, slots, sink):
+    def take_rows(rows, slots, sink, xplan=None):
         return rows[slots]                                      # torch indexing: dense gradient of the rows buffer
 
     @staticmethod
