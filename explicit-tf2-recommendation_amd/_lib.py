@@ -71,6 +71,8 @@ SIGNATURES = {
     "rec_colsort_shard_map_i64": (i32, [p, p, p, p, i64, i32, i64, i32, p, p, p, p, p, p]),
     "rec_colsort_shard_map_fixed_i64": (i32, [p, p, p, p, i64, i32, i64, i32, i64, p, p, p, p, p, p]),
     "rec_emb_gather_lists_f32": (i32, [p, i64, i32, i64, p, i32, i64, p, p, p]),
+    "rec_block_copy": (i32, [p, i32, i64, p, p]),
+    "rec_auc_hist_update_f32": (i32, [p, p, i64, p, i32, p, p, i32, p, p]),
     "rec_shard_slab_map_i64": (i32, [p, p, p, p, i64, i64, i32, i64, p, p, p, p]),
     "rec_shard_slab_map_uslot_i64": (i32, [p, p, p, p, i64, i64, i32, i64, p, p, p, p, p]),
     "rec_dedup_plan_sorted_slabs_i64": (i32, [p, i32, i64, i64, p, p, p, p, p, sz, p]),
@@ -90,6 +92,7 @@ SIGNATURES = {
     "rec_deepfm_k0t_f32": (i32, [p, i32, p, p]),
     "rec_deepfm_fused3_main_f32": (i32, [p, i64, i64, p, i32, i64] + [p] * 14 + [p]),
     "rec_deepfm_fused3_main_direct_f32": (i32, [p, i64, i64, p, i32, i64] + [p] * 14 + [p, p, p] + [p]),
+    "rec_deepfm_fused3_main_direct_adv_f32": (i32, [p, i64, i64, p, i32, i64] + [p] * 14 + [p, p, p] + [p, p, i64, p] + [p]),
     "rec_deepfm_fused_post_direct_adam_f32": (i32, [i32, i64] + [p] * 19 + [p, i64, i64, p, p, p, p, i64, f32, f32, f32,
                                                                           f32, p]),
     "rec_colseg_sum_f32": (i32, [p, p, p, p, p, p, i64, i32, p, p, p, p, p]),

@@ -51,10 +51,21 @@ __device__ __forceinline__ float row16_allsum(float v) {
 // launch, the catch-up of lazily evaluated rows -- therefore produces the same bits:
 //   touched   m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2 ; x <- x - lr_t m / (sqrt(v) + eps)
 //   untouched m <- b1 m            ; v <- b2 v              ; x <- x - lr_t m / (sqrt(v) + eps)   (Keras' dense sweep)
+// The quotient: hardware square root and reciprocal (v_sqrt_f32, v_rcp_f32: 1 ulp each) and ONE pinned fma, not the
+// correctly rounded sqrtf() and `/` (35 instruction slots per element and step against 14 -- and the lazily evaluated Adam
+// replays ~47 steps per row it touches at 10M rows: that kernel is arithmetic-bound).  m and v are unaffected; the step
+// lr_t m / (sqrt(v) + eps) is off by <= ~3 ulp of ITSELF, i.e. far below one ulp of x: x equals the correctly rounded
+// evaluation in most steps and differs by one ulp of x in the rest (tests hold the tables to the oracle within 2e-5).
+// -DREC_ADAM_IEEE restores the correctly rounded form in every kernel at once.
 __device__ __forceinline__ float adam_step_x(float x, float m, float v, float lr_t, float eps) {
   const float num = lr_t * m;                        // a product that feeds a division: nothing to fuse
+#ifdef REC_ADAM_IEEE
   const float den = sqrtf(v) + eps;
   return x - num / den;
+#else
+  const float den = __builtin_amdgcn_sqrtf(v) + eps;
+  return __builtin_fmaf(-num, __builtin_amdgcn_rcpf(den), x);
+#endif
 }
 __device__ __forceinline__ void adam_touch(float& x, float& m, float& v, float g, float lr_t, float b1, float b2,
                                            float eps) {

@@ -1160,63 +1160,104 @@ struct CatchArgs {
   float* table; int64_t V; float* m_e; float* v_e; int64_t ldm; float* m_w; float* v_w; int64_t ldw;
   const int32_t* last; const int64_t* step_dev; const float* lr_tab; int64_t n_tab; float b1, b2, eps;
 };
-// A workgroup takes CATCH_R consecutive slots (unique ids of the plan, or table rows for the flush), looks up how many
-// steps each of them has to replay and hands the rows to its waves in DESCENDING order of that count: a wave of 4 rows x
-// 16 elements runs as long as its longest row, and with the pending counts of a batch spread geometrically (mean ~47 at
-// 213k of 10M rows per step) unsorted waves ran twice the mean.  The first-order weights of the 64 rows follow on the
-// first wave, one lane per row, in the same order.
-constexpr int CATCH_R = 64;
-__global__ __launch_bounds__(CATCH_R * E16) void adam_keras_catchup_kernel(CatchArgs a) {
+// A workgroup (256 threads) takes CATCH_R = 64 consecutive slots (unique ids of the plan, or table rows for the flush),
+// FOUR lanes per row: lane q owns elements 4q .. 4q+3 of the row (lane 0 also the first-order weight) -- four or five
+// independent chains per lane, 512 rows in flight per CU.  The kernel is a chain of latencies, not arithmetic (at 1M rows
+// the arithmetic is ~25 us of the chip, the first form -- 16 lanes per row, 128 rows in flight per CU, a global load of
+// lr_t in every replayed step, three dependent round trips before the first of them -- took 78 us):
+//   trip 1   plan word of the slot (col_nu of its column beside it)
+//   trip 2   last[id] AND the row's x / m / v pieces (their addresses only need the id)
+//   LDS      the rows change hands: how many steps each one replays is known now, and the rows are handed out again in
+//            DESCENDING order of that count -- a wave of 16 rows runs as long as its longest row, and with the pending
+//            counts of a batch spread geometrically (mean ~47 at 213k of 10M rows per step) unsorted waves ran twice the
+//            mean
+//   replay   lr_t of the last CATCH_LR steps comes from LDS (older ones from the table in memory)
+constexpr int CATCH_R = 64, CATCH_T = 256, CATCH_LR = 1024;
+__global__ __launch_bounds__(CATCH_T) void adam_keras_catchup_kernel(CatchArgs a) {
+  __shared__ float4 x_s[CATCH_R][4], m_s[CATCH_R][4], v_s[CATCH_R][4];
+  __shared__ float xw_s[CATCH_R], mw_s[CATCH_R], vw_s[CATCH_R];
   __shared__ int64_t id_s[CATCH_R];
-  __shared__ int j0_s[CATCH_R], k_s[CATCH_R];
+  __shared__ int k_s[CATCH_R];
   __shared__ unsigned char ord[CATCH_R];
-  const int tid = threadIdx.x;
+  __shared__ float lr_s[CATCH_LR];
+  const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
   const int64_t nslot = a.col_uid ? a.B * a.F : a.V;
   const int64_t j1 = *a.step_dev;
-  if (tid < CATCH_R) {
-    const int64_t slot = (int64_t)blockIdx.x * CATCH_R + tid;
-    int64_t id = -1;
-    if (slot < nslot) {
-      if (a.col_uid) {
-        const int f = (int)(slot / a.B);
-        const int64_t u = slot - (int64_t)f * a.B;
-        if (u < a.col_nu[f]) id = a.col_uid[(int64_t)f * a.B + u];
-      } else {
-        id = slot;
-      }
-    }
-    int j0 = 0, k = 0;
-    if ((uint64_t)id < (uint64_t)a.V) {
-      j0 = a.last[id];
-      k = j1 > j0 ? (int)(j1 - j0) : 0;
-    }
-    id_s[tid] = id; j0_s[tid] = j0; k_s[tid] = k;
+#pragma unroll
+  for (int i = tid; i < CATCH_LR; i += CATCH_T) {          // lr_s[i] = lr_t of step j1 - i
+    const int64_t j = j1 - i;
+    lr_s[i] = j >= 1 ? a.lr_tab[(j < a.n_tab ? j : a.n_tab) - 1] : 0.f;
+  }
+  const int64_t slot = (int64_t)blockIdx.x * CATCH_R + r;
+  int64_t id = -1;
+  if (a.col_uid) {
+    const int64_t sc = slot < nslot ? slot : nslot - 1;    // unconditional loads, judged afterwards
+    const int f = (int)(sc / a.B);
+    const int64_t u = sc - (int64_t)f * a.B;
+    const int nu = a.col_nu[f];
+    const int64_t cand = a.col_uid[sc];
+    if (slot < nslot && u < nu) id = cand;
+  } else if (slot < nslot) {
+    id = slot;
+  }
+  const bool ok = (uint64_t)id < (uint64_t)a.V;
+  const int64_t idc = ok ? id : 0;
+  const int j0 = a.last[idc];
+  float4 x4 = *reinterpret_cast<const float4*>(a.table + idc * LD + 4 * q);
+  float4 m4 = *reinterpret_cast<const float4*>(a.m_e + idc * a.ldm + 4 * q);
+  float4 v4 = *reinterpret_cast<const float4*>(a.v_e + idc * a.ldm + 4 * q);
+  x_s[r][q] = x4; m_s[r][q] = m4; v_s[r][q] = v4;
+  if (q == 0) {
+    xw_s[r] = a.table[idc * LD + E16];
+    mw_s[r] = a.m_w[idc * a.ldw];
+    vw_s[r] = a.v_w[idc * a.ldw];
+    id_s[r] = id;
+    k_s[r] = (ok && j1 > j0) ? (int)(j1 - j0) : 0;
   }
   __syncthreads();
   if (tid < CATCH_R) {
     const int k = k_s[tid];
     int rank = 0;
 #pragma unroll 8
-    for (int q = 0; q < CATCH_R; ++q) rank += (k_s[q] > k || (k_s[q] == k && q < tid)) ? 1 : 0;
+    for (int c = 0; c < CATCH_R; ++c) rank += (k_s[c] > k || (k_s[c] == k && c < tid)) ? 1 : 0;
     ord[rank] = (unsigned char)tid;
   }
   __syncthreads();
-  for (int part = 0; part < 2; ++part) {                 // 0: the 16 embedding elements of every row, 1: its w element
-    if (part == 1 && tid >= CATCH_R) break;
-    const int r = part == 0 ? ord[tid >> 4] : ord[tid];
-    const int k = k_s[r];
-    if (k <= 0) continue;
-    const int64_t id = id_s[r];
-    const int e = tid & 15;
-    float* px = part == 0 ? a.table + id * LD + e : a.table + id * LD + E16;
-    float* pm = part == 0 ? a.m_e + id * a.ldm + e : a.m_w + id * a.ldw;
-    float* pv = part == 0 ? a.v_e + id * a.ldm + e : a.v_w + id * a.ldw;
-    float x = *px, m = *pm, v = *pv;
-    if (m == 0.f && v == 0.f) continue;                  // x - lr*0/(0+eps) = x: a row that was never touched stays put
-    const int64_t j0 = j0_s[r];
-    for (int64_t j = j0 + 1; j <= j1; ++j)
-      adam_decay(x, m, v, a.lr_tab[(j < a.n_tab ? j : a.n_tab) - 1], a.b1, a.b2, a.eps);
-    *px = x; *pm = m; *pv = v;
+  const int rr = ord[r];                                   // the row this lane group replays
+  const int k = k_s[rr];
+  if (k <= 0) return;
+  const int64_t rid = id_s[rr];
+  x4 = x_s[rr][q]; m4 = m_s[rr][q]; v4 = v_s[rr][q];
+  float xw = 0.f, mw = 0.f, vw = 0.f;
+  if (q == 0) { xw = xw_s[rr]; mw = mw_s[rr]; vw = vw_s[rr]; }
+  // (a row that was never touched -- m = v = 0 -- stays put: x - lr*0/(0+eps) = x; skipping it is only cheaper)
+  const bool any_e = m4.x != 0.f || v4.x != 0.f || m4.y != 0.f || v4.y != 0.f || m4.z != 0.f || v4.z != 0.f ||
+                     m4.w != 0.f || v4.w != 0.f;
+  const bool any_w = q == 0 && (mw != 0.f || vw != 0.f);
+  if (!any_e && !any_w) return;
+  for (int i = k - 1; i >= 0; --i) {                       // step j1 - i
+    float lr;
+    if (i < CATCH_LR) {
+      lr = lr_s[i];
+    } else {
+      const int64_t j = j1 - i;
+      lr = a.lr_tab[(j < a.n_tab ? j : a.n_tab) - 1];
+    }
+    adam_decay(x4.x, m4.x, v4.x, lr, a.b1, a.b2, a.eps);
+    adam_decay(x4.y, m4.y, v4.y, lr, a.b1, a.b2, a.eps);
+    adam_decay(x4.z, m4.z, v4.z, lr, a.b1, a.b2, a.eps);
+    adam_decay(x4.w, m4.w, v4.w, lr, a.b1, a.b2, a.eps);
+    if (q == 0) adam_decay(xw, mw, vw, lr, a.b1, a.b2, a.eps);
+  }
+  if (any_e) {
+    *reinterpret_cast<float4*>(a.table + rid * LD + 4 * q) = x4;
+    *reinterpret_cast<float4*>(a.m_e + rid * a.ldm + 4 * q) = m4;
+    *reinterpret_cast<float4*>(a.v_e + rid * a.ldm + 4 * q) = v4;
+  }
+  if (any_w) {
+    a.table[rid * LD + E16] = xw;
+    a.m_w[rid * a.ldw] = mw;
+    a.v_w[rid * a.ldw] = vw;
   }
 }
 __global__ __launch_bounds__(256) void fill_last_kernel(int32_t* __restrict__ last, int64_t V,
@@ -1510,6 +1551,10 @@ static int catchup_args_ok(const float* table, int64_t ld, int64_t V, const floa
       ld_state < E16 || ld_wstate < 1)
     return REC_E_ARG;
   if (ld != LD) return REC_E_UNSUPPORTED;
+  // the rows' x / m / v travel as 16-byte pieces
+  if ((ld_state & 3) != 0 || (reinterpret_cast<uintptr_t>(table) & 15) != 0 || (reinterpret_cast<uintptr_t>(m_e) & 15) != 0 ||
+      (reinterpret_cast<uintptr_t>(v_e) & 15) != 0)
+    return REC_E_UNSUPPORTED;
   return REC_OK;
 }
 
@@ -1523,7 +1568,7 @@ extern "C" int rec_adam_keras_catchup_f32(const int64_t* col_uid, const int32_t*
   if (rc != REC_OK) return rc;
   CatchArgs a{col_uid, col_nu, B, F, table, V, m_e, v_e, ld_state, m_w, v_w, ld_wstate, last, step_dev, lr_table, n_table,
               b1, b2, eps};
-  hipLaunchKernelGGL(adam_keras_catchup_kernel, dim3((unsigned)ceil_div64(B * F, CATCH_R)), dim3(CATCH_R * E16), 0,
+  hipLaunchKernelGGL(adam_keras_catchup_kernel, dim3((unsigned)ceil_div64(B * F, CATCH_R)), dim3(CATCH_T), 0,
                      as_stream(stream), a);
   REC_LAUNCH_CHECK();
   return REC_OK;
@@ -1538,7 +1583,7 @@ extern "C" int rec_adam_keras_flush_f32(float* table, int64_t ld, int64_t V, flo
   if (rc != REC_OK) return rc;
   CatchArgs a{nullptr, nullptr, 0, 0, table, V, m_e, v_e, ld_state, m_w, v_w, ld_wstate, last, step_dev, lr_table,
               n_table, b1, b2, eps};
-  hipLaunchKernelGGL(adam_keras_catchup_kernel, dim3((unsigned)ceil_div64(V, CATCH_R)), dim3(CATCH_R * E16), 0,
+  hipLaunchKernelGGL(adam_keras_catchup_kernel, dim3((unsigned)ceil_div64(V, CATCH_R)), dim3(CATCH_T), 0,
                      as_stream(stream), a);
   REC_LAUNCH_CHECK();
   hipLaunchKernelGGL(fill_last_kernel, dim3((unsigned)ceil_div64(V, 256)), dim3(256), 0, as_stream(stream), last, V,

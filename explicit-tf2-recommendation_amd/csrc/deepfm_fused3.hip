@@ -66,6 +66,7 @@ struct F3Args {
   float* dK0part; float* small;
   int* oob;
   const int32_t* dloc; const int32_t* col_nu; float* g_embed;     // direct mode
+  int64_t* step_dev; const float* lr_tab; int64_t n_tab; float* lr_t_dev;   // optional: the optimizer's step counter
 #ifdef REC_FUSED_STAMPS
   unsigned long long* stamps;
 #endif
@@ -191,6 +192,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int th_ = tid & 255;                               // thread index inside the half
   STAMP3(0);
 
+  // the device-side step counter of the optimizer (rec_adam_advance_f32's job, without its launch): this kernel does not
+  // read it; the catch-up kernel before it needs the old value, the post launch and the dense update after it the new one
+  if (a.step_dev && blockIdx.x == 0 && tid == 0) {
+    const int64_t s = *a.step_dev + 1;
+    *a.step_dev = s;
+    *a.lr_t_dev = a.lr_tab[(s < a.n_tab ? s : a.n_tab) - 1];
+  }
   int* sync_cnt = reinterpret_cast<int*>(lds + cv.flags);   // arrival counters of the half-workgroup syncs
   if (tid < 8) sync_cnt[tid] = 0;                          // (first used behind barrier 0)
 
@@ -669,8 +677,10 @@ static int launch_fused3(const float* table, int64_t ld, int64_t V, const int64_
                          const float* bias, const float* K0, const float* K0T, const float* b0, const float* K1,
                          const float* b1, const float* K2, const float* b2, const float* label, float* gz, float* vals,
                          float* prob, int* oob_flag, void* workspace, const int32_t* dloc, const int32_t* col_nu,
-                         float* g_embed, bool direct, void* stream) {
+                         float* g_embed, bool direct, void* stream, int64_t* step_dev = nullptr,
+                         const float* lr_tab = nullptr, int64_t n_tab = 0, float* lr_t_dev = nullptr) {
   if (B <= 0 || F <= 0 || V <= 0) return REC_E_ARG;
+  if (step_dev && (!lr_tab || !lr_t_dev || n_tab <= 0)) return REC_E_ARG;
   if (F > 28 || F > REC_MAX_COLS || V >= (int64_t(1) << 31)) return REC_E_UNSUPPORTED;
   if (direct ? ld != 32 : (ld < 20 || (ld & 3) != 0)) return REC_E_UNSUPPORTED;
   if (!table || !cols_host || !bias || !K0 || !K0T || !b0 || !K1 || !b1 || !K2 || !b2 || !label || !gz || !vals ||
@@ -703,10 +713,10 @@ static int launch_fused3(const float* table, int64_t ld, int64_t V, const int64_
   if (!stamps && hipMalloc(&stamps, sizeof(unsigned long long) * 12 * NWV * 65536) != hipSuccess) return REC_E_ARG;
   g_fused3_stamps = stamps;
   F3Args a{table, V, (int)ld, bias, K0, K0T, b0, K1, b1, K2, b2, label, B, F, gz, vals, prob, dK0part, small, oob_flag,
-           dloc, col_nu, g_embed, stamps};
+           dloc, col_nu, g_embed, step_dev, lr_tab, n_tab, lr_t_dev, stamps};
 #else
   F3Args a{table, V, (int)ld, bias, K0, K0T, b0, K1, b1, K2, b2, label, B, F, gz, vals, prob, dK0part, small, oob_flag,
-           dloc, col_nu, g_embed};
+           dloc, col_nu, g_embed, step_dev, lr_tab, n_tab, lr_t_dev};
 #endif
   hipStream_t st = as_stream(stream);
 #define LAUNCH3(DIR, KL)                                                                                         \
@@ -744,4 +754,20 @@ extern "C" int rec_deepfm_fused3_main_direct_f32(const float* table, int64_t ld,
                                                  void* stream) {
   return launch_fused3(table, ld, V, cols_host, F, B, bias, K0, K0T, b0, K1, b1, K2, b2, label, gz, vals, prob, oob_flag,
                        workspace, dloc, col_nu, g_embed_rows, true, stream);
+}
+
+// rec_deepfm_fused3_main_direct_f32 + rec_adam_advance_f32 in one launch: *step_dev += 1 and *lr_t_dev =
+// lr_table[min(*step_dev, n_table) - 1] are done by the fused kernel's first thread (the kernel itself reads neither), so the
+// post launch and the dense update behind it see the new step, the catch-up kernel before it saw the old one.
+extern "C" int rec_deepfm_fused3_main_direct_adv_f32(const float* table, int64_t ld, int64_t V,
+                                                     const int64_t* const* cols_host, int F, int64_t B, const float* bias,
+                                                     const float* K0, const float* K0T, const float* b0, const float* K1,
+                                                     const float* b1, const float* K2, const float* b2, const float* label,
+                                                     float* gz, float* vals, float* prob, int* oob_flag, void* workspace,
+                                                     const int32_t* dloc, const int32_t* col_nu, float* g_embed_rows,
+                                                     int64_t* step_dev, const float* lr_table, int64_t n_table,
+                                                     float* lr_t_dev, void* stream) {
+  if (!step_dev || !lr_table || !lr_t_dev || n_table <= 0) return REC_E_ARG;
+  return launch_fused3(table, ld, V, cols_host, F, B, bias, K0, K0T, b0, K1, b1, K2, b2, label, gz, vals, prob, oob_flag,
+                       workspace, dloc, col_nu, g_embed_rows, true, stream, step_dev, lr_table, n_table, lr_t_dev);
 }

@@ -49,6 +49,95 @@ extern "C" int rec_index_pack_i64(const int64_t* const* cols_host, int F, int64_
   return REC_OK;
 }
 
+// Staging of input batches (model_manager.py, the compiled train loop): n device arrays of the same size -> consecutive
+// slices of ONE block, one launch (a torch.stack of 26 columns costs ~35 us of host time, and the loop stages a batch
+// per step).  16-byte pieces when everything is 16-byte aligned, 4-byte words otherwise.
+struct BlockSrcs {
+  const void* p[256];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void block_copy_kernel(BlockSrcs srcs, int64_t units, T* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= units) return;
+  const int s = (int)blockIdx.y;
+  out[(int64_t)s * units + t] = reinterpret_cast<const T*>(srcs.p[s])[t];
+}
+
+extern "C" int rec_block_copy(const void* const* srcs_host, int n, int64_t bytes_each, void* out, void* stream) {
+  if (!srcs_host || n <= 0 || bytes_each < 0 || (bytes_each & 3) != 0) return REC_E_ARG;
+  if (bytes_each == 0) return REC_OK;
+  if (!out) return REC_E_ARG;
+  for (int s0 = 0; s0 < n; s0 += 256) {
+    const int ns = n - s0 < 256 ? n - s0 : 256;
+    BlockSrcs b;
+    bool vec = (bytes_each & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    for (int s = 0; s < ns; ++s) {
+      if (!srcs_host[s0 + s]) return REC_E_ARG;
+      b.p[s] = srcs_host[s0 + s];
+      vec = vec && (reinterpret_cast<uintptr_t>(b.p[s]) & 15) == 0;
+    }
+    char* o = reinterpret_cast<char*>(out) + (int64_t)s0 * bytes_each;
+    if (vec) {
+      const int64_t units = bytes_each / 16;
+      hipLaunchKernelGGL(block_copy_kernel<uint4>, dim3((unsigned)ceil_div64(units, 256), ns), dim3(256), 0,
+                         as_stream(stream), b, units, reinterpret_cast<uint4*>(o));
+    } else {
+      const int64_t units = bytes_each / 4;
+      hipLaunchKernelGGL(block_copy_kernel<uint32_t>, dim3((unsigned)ceil_div64(units, 256), ns), dim3(256), 0,
+                         as_stream(stream), b, units, reinterpret_cast<uint32_t*>(o));
+    }
+    REC_LAUNCH_CHECK();
+  }
+  return REC_OK;
+}
+
+// tf.keras.metrics.AUC(num_thresholds) as a streaming histogram (2.FM/ModelManager.py:106,180): bucket k of an example =
+// the number of thresholds strictly below its prediction; hist [2][n_thr + 1] int64 = examples per (label > 0.5, bucket),
+// accumulated with integer atomics (exact, order-independent).  Also adds the n_steps per-step losses onto *loss_acc
+// (double; one thread, fixed order).
+__global__ __launch_bounds__(256) void auc_hist_kernel(const float* __restrict__ prob, const float* __restrict__ label,
+                                                       int64_t n, const float* __restrict__ thr, int n_thr,
+                                                       unsigned long long* __restrict__ hist,
+                                                       const float* __restrict__ loss_steps, int n_steps,
+                                                       double* __restrict__ loss_acc) {
+  extern __shared__ unsigned int h_s[];                    // [2][n_thr + 1]
+  const int nb = 2 * (n_thr + 1);
+  for (int i = threadIdx.x; i < nb; i += 256) h_s[i] = 0u;
+  __syncthreads();
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+    const float p = prob[t];
+    int lo = 0, hi = n_thr;                                // first threshold that is not below p
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (thr[mid] < p) lo = mid + 1; else hi = mid;
+    }
+    atomicAdd(&h_s[(label[t] > 0.5f ? n_thr + 1 : 0) + lo], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb; i += 256)
+    if (h_s[i]) atomicAdd(&hist[i], (unsigned long long)h_s[i]);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && loss_steps && loss_acc) {
+    double s = 0.0;
+    for (int i = 0; i < n_steps; ++i) s += (double)loss_steps[i];
+    *loss_acc += s;
+  }
+}
+
+extern "C" int rec_auc_hist_update_f32(const float* prob, const float* label, int64_t n, const float* thresholds,
+                                       int n_thresholds, int64_t* hist, const float* loss_steps, int n_steps,
+                                       double* loss_acc, void* stream) {
+  if (n < 0 || n_thresholds <= 0 || n_thresholds > 4096 || n_steps < 0) return REC_E_ARG;
+  if (!hist || !thresholds || (n > 0 && (!prob || !label)) || (n_steps > 0 && (!loss_steps || !loss_acc))) return REC_E_ARG;
+  if (n == 0 && n_steps == 0) return REC_OK;
+  int64_t blocks = ceil_div64(n > 0 ? n : 1, 256 * 8);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(auc_hist_kernel, dim3((unsigned)blocks), dim3(256), sizeof(unsigned int) * 2 * (n_thresholds + 1),
+                     as_stream(stream), prob, label, n, thresholds, n_thresholds,
+                     reinterpret_cast<unsigned long long*>(hist), loss_steps, n_steps, loss_acc);
+  REC_LAUNCH_CHECK();
+  return REC_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2  plain gather (table row stride ld, output dense [n,E])
 // ------------------------------------------------------------------------------------------------

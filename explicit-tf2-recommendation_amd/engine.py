@@ -475,11 +475,19 @@ class DeepFMFusedStep:
                     _p(L.MLP_layer2.kernel_0), _p(L.MLP_layer2.bias_0), _p(label), _p(self.gz), _p(self.vals),
                     self._pprob(), _p(self.oob), _p(self.ws), st), "rec_deepfm_fused3_main_f32")
                 return
-            check(lib.rec_deepfm_fused3_main_direct_f32(
-                _p(emb), emb.stride(0), self.V, arr, F, self.B, _p(L.bias), _p(L.MLP_layer1.kernel_0), _p(self._k0t),
-                _p(L.MLP_layer1.bias_0), _p(L.MLP_layer1.kernel_1), _p(L.MLP_layer1.bias_1), _p(L.MLP_layer2.kernel_0),
-                _p(L.MLP_layer2.bias_0), _p(label), _p(self.gz), _p(self.vals), self._pprob(), _p(self.oob), _p(self.ws),
-                _p(pl["dloc"]), _p(pl["col_nu"]), _p(self.g_embed_rows), st), "rec_deepfm_fused3_main_direct_f32")
+            head = (_p(emb), emb.stride(0), self.V, arr, F, self.B, _p(L.bias), _p(L.MLP_layer1.kernel_0), _p(self._k0t),
+                    _p(L.MLP_layer1.bias_0), _p(L.MLP_layer1.kernel_1), _p(L.MLP_layer1.bias_1), _p(L.MLP_layer2.kernel_0),
+                    _p(L.MLP_layer2.bias_0), _p(label), _p(self.gz), _p(self.vals), self._pprob(), _p(self.oob), _p(self.ws),
+                    _p(pl["dloc"]), _p(pl["col_nu"]), _p(self.g_embed_rows))
+            if self._fused_lazy():
+                # the optimizer's device-side step counter advances inside this launch (the kernel reads neither word):
+                # the catch-up above saw the old step, the post launch and the dense update below see the new one
+                check(lib.rec_deepfm_fused3_main_direct_adv_f32(*head, _p(self._step_dev), _p(self._lr_tab),
+                                                                self._lr_tab.numel(), _p(self._lr_t_dev), st),
+                      "rec_deepfm_fused3_main_direct_adv_f32")
+                self._advanced = True
+            else:
+                check(lib.rec_deepfm_fused3_main_direct_f32(*head, st), "rec_deepfm_fused3_main_direct_f32")
             return
         if not self.direct:
             check(lib.rec_deepfm_fused_main_f32(
@@ -508,8 +516,10 @@ class DeepFMFusedStep:
             params = dict(self.layer.named_parameters())
             pe = params["embed.embeddings"]
             (me, ve), (mw, vw) = self.state["embed.embeddings"], self.state["w.embeddings"]
-            check(lib.rec_adam_advance_f32(_p(self._step_dev), _p(self._lr_tab), self._lr_tab.numel(),
-                                           _p(self._lr_t_dev), st), "rec_adam_advance_f32")
+            if not getattr(self, "_advanced", False):        # (the v3 fused launch has already advanced the counter)
+                check(lib.rec_adam_advance_f32(_p(self._step_dev), _p(self._lr_tab), self._lr_tab.numel(),
+                                               _p(self._lr_t_dev), st), "rec_adam_advance_f32")
+            self._advanced = False
             check(lib.rec_deepfm_fused_post_direct_adam_dev_f32(
                 self.F, self.B, _p(self.gz), _p(self.vals), _p(g["MLP_layer1.kernel_0"]), _p(g["MLP_layer1.bias_0"]),
                 _p(g["MLP_layer1.kernel_1"]), _p(g["MLP_layer1.bias_1"]), _p(g["MLP_layer2.kernel_0"]),

@@ -208,16 +208,25 @@ class ModelManager:
         return np.array([-1e-7] + [(i + 1) / (n - 1) for i in range(n - 2)] + [1.0 + 1e-7], np.float64)
 
     def _metric_update_dev(self, loss, target, prob, n_steps=1):
+        """One launch (rec_auc_hist_update_f32): the predictions' buckets counted with integer atomics, the per-step losses
+        added in double -- nothing is read back until _metric_result()."""
         d = self._dev_metric
         if d is None:
             dev = loss.device
             d = self._dev_metric = {"thr": torch.from_numpy(self._auc_thresholds().astype(np.float32)).to(dev),
-                                    "hist": torch.zeros(2 * (self.AUC_THRESHOLDS + 1), dtype=torch.float32, device=dev),
+                                    "hist": torch.zeros(2 * (self.AUC_THRESHOLDS + 1), dtype=torch.int64, device=dev),
                                     "loss": torch.zeros(1, dtype=torch.float64, device=dev), "n": 0}
-        y = target.reshape(-1)
-        k = torch.bucketize(prob.reshape(-1).contiguous(), d["thr"], right=False)       # thresholds strictly below p
-        d["hist"].index_add_(0, k + (y > 0.5).to(torch.int64) * (self.AUC_THRESHOLDS + 1), torch.ones_like(y))
-        d["loss"] += loss.reshape(-1)[:n_steps].to(torch.float64).sum()
+        y, p, ls = target.reshape(-1), prob.reshape(-1), loss.reshape(-1)
+        if y.dtype != torch.float32 or not y.is_contiguous():
+            y = y.to(torch.float32).contiguous()
+        if p.dtype != torch.float32 or not p.is_contiguous():
+            p = p.to(torch.float32).contiguous()
+        if ls.dtype != torch.float32 or not ls.is_contiguous():
+            ls = ls.to(torch.float32).contiguous()
+        assert y.numel() == p.numel() and ls.numel() >= n_steps
+        ops.check(ops.lib.rec_auc_hist_update_f32(ops._ptr(p), ops._ptr(y), p.numel(), ops._ptr(d["thr"]),
+                                                  self.AUC_THRESHOLDS, ops._ptr(d["hist"]), ops._ptr(ls), int(n_steps),
+                                                  ops._ptr(d["loss"]), ops._stream()), "rec_auc_hist_update_f32")
         d["n"] += n_steps
 
     def _metric_update(self, loss, target, output):
@@ -408,12 +417,62 @@ class ModelManager:
         the step's own per-step buffers, for the metrics."""
         R = self.steps_per_call
         step = self._eng[1]
-        ring = self.__dict__.setdefault("_chunk_ring", [[None] * R, [None] * R])
+        ring = self.__dict__.setdefault("_chunk_ring", [None, None])
 
-        def stage(chunk, half):
-            for j, b in enumerate(chunk):
-                ring[half][j] = self._fill(ring[half][j], b)
-            return ring[half][:len(chunk)]
+        def half_of(h, example):
+            """R staging slots whose tensors of one (dtype, shape) are slices of ONE block [R, members, ...]: a chunk of
+            device-resident batches is staged by one rec_block_copy launch per block, and the labels of the chunk are a
+            view of their block"""
+            if ring[h] is None:
+                proto = self._fill(None, example)            # (normalises dtypes; its blocks give the groups)
+                blocks, slots = [], [{"__groups__": []} for _ in range(R)]
+                for members, blk in proto["__groups__"]:
+                    big = torch.empty((R,) + tuple(blk.shape), dtype=blk.dtype, device=blk.device)
+                    blocks.append((members, big))
+                    for j in range(R):
+                        slots[j]["__groups__"].append((members, big[j]))
+                        for g, nme in enumerate(members):
+                            slots[j][nme] = big[j][g]
+                ring[h] = (blocks, slots)
+            return ring[h]
+
+        def stage(chunk, h):
+            blocks, slots = half_of(h, chunk[0])
+            n_names = len(slots[0]) - 1
+            fast, todo = True, []
+            for members, big in blocks:                      # device-resident batches of exactly the staged layout?
+                dt, shp, ptrs = big.dtype, big.shape[2:], []
+                for b in chunk:
+                    if len(b) != n_names:
+                        fast = False
+                        break
+                    for nme in members:
+                        t = b.get(nme)
+                        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype is dt and t.shape == shp and
+                                t.is_contiguous()):
+                            fast = False
+                            break
+                        ptrs.append(t.data_ptr())
+                    if not fast:
+                        break
+                if not fast:
+                    break
+                todo.append((big, ptrs))
+            if fast:
+                for big, ptrs in todo:
+                    arr = (ops.C.c_void_p * len(ptrs))(*ptrs)
+                    ops.check(ops.lib.rec_block_copy(arr, len(ptrs), big[0][0].numel() * big.element_size(), ops._ptr(big),
+                                                     ops._stream()), "rec_block_copy")
+            else:
+                for j, b in enumerate(chunk):
+                    self._fill(slots[j], b)
+            return slots[:len(chunk)]
+
+        def labels_of(h, n):
+            for members, big in ring[h][0]:
+                if self.label_name in members:
+                    return big[:n, members.index(self.label_name)]
+            raise KeyError(self.label_name)
 
         chunks = [order[i:i + R] for i in range(0, len(order), R)]
         cur = stage(chunks[0], 0)
@@ -421,8 +480,7 @@ class ModelManager:
             nxt = stage(chunks[c + 1], (c + 1) % 2) if c + 1 < len(chunks) else None
             step.many(cur, self.label_name, then=nxt)
             n = len(cur)
-            y = torch.cat([s_[self.label_name].reshape(-1) for s_ in cur])
-            self._metric_update_dev(step.loss_steps[:n], y, step.prob_steps[:n].reshape(-1), n)
+            self._metric_update_dev(step.loss_steps[:n], labels_of(c % 2, n), step.prob_steps[:n], n)
             cur = nxt
         self._pending = None
 

@@ -57,6 +57,17 @@ int rec_version(void);
 int rec_index_pack_i64(const int64_t* const* cols_host, int F, int64_t rows, int64_t* X, int64_t ldx,
                        int64_t col0, void* stream);
 
+/* Staging of input batches for the compiled train loop (2.FM/ModelManager.py:183-199 iterates a tf.data pipeline; here
+ * the batches of a chunk of steps are copied into fixed device buffers so that the captured step sees constant addresses):
+ * n device arrays of bytes_each bytes (a multiple of 4) -> out[s * bytes_each ...], one launch.  srcs_host: HOST array of
+ * n device pointers. */
+int rec_block_copy(const void* const* srcs_host, int n, int64_t bytes_each, void* out, void* stream);
+/* tf.keras.metrics.AUC(num_thresholds) / Mean(loss) accumulated on the device (2.FM/ModelManager.py:106-107,180-181):
+ * hist [2][n_thresholds + 1] int64 += examples per (label > 0.5, number of thresholds strictly below the prediction);
+ * *loss_acc (double) += the n_steps per-step losses.  Integer atomics: exact and order-independent. */
+int rec_auc_hist_update_f32(const float* prob, const float* label, int64_t n, const float* thresholds, int n_thresholds,
+                            int64_t* hist, const float* loss_steps, int n_steps, double* loss_acc, void* stream);
+
 /* Tables: row-major fp32 with a row stride `ld` >= E floats (dense table: ld = E).  The FM-family layers keep
  * `embed` [V,E] and `w` [V,1] of one id in ONE 128-byte line -- fused layout, row = [embed(E) | w | pad] with
  * ld = next_pow2(E+1) >= 16, passed as embed = base, w = base + E, ld_e = ld_w = ld -- because a random row
@@ -175,6 +186,15 @@ float rec_adam_lr_t_f32(float lr, float b1, float b2, int64_t t);
 /* Device-side step counter: *step_dev += 1, *lr_t_dev = lr_table[min(*step_dev, n_table) - 1] (one tiny launch).  With it
  * a train step holds no per-step host scalar and can be captured in a hipGraph. */
 int rec_adam_advance_f32(int64_t* step_dev, const float* lr_table, int64_t n_table, float* lr_t_dev, void* stream);
+/* rec_deepfm_fused3_main_direct_f32 (below) with that advance done by the fused kernel's first thread -- the kernel reads
+ * neither word, the launches behind it on the stream see the new step: one launch less per train step. */
+int rec_deepfm_fused3_main_direct_adv_f32(const float* table, int64_t ld, int64_t V, const int64_t* const* cols_host, int F,
+                                          int64_t B, const float* bias, const float* K0, const float* K0T, const float* b0,
+                                          const float* K1, const float* b1, const float* K2, const float* b2,
+                                          const float* label, float* gz, float* vals, float* prob, int* oob_flag,
+                                          void* workspace, const int32_t* dloc, const int32_t* col_nu, float* g_embed_rows,
+                                          int64_t* step_dev, const float* lr_table, int64_t n_table, float* lr_t_dev,
+                                          void* stream);
 /* rec_adam_dense_f32 on up to 16 parameters in ONE launch, step size read from device memory (host arrays of device
  * pointers, copied into the kernel arguments). */
 int rec_adam_dense_multi_f32(int n_tensors, float* const* var, float* const* m, float* const* v, const float* const* g,
