@@ -653,3 +653,37 @@ def test_sharded_layers_two_ranks_hip_kernels(family):
     result = mgr.dict()
     mp.spawn(_sharded_layer_worker, args=(world, _free_port(), family, V, B, result), nprocs=world, join=True)
     assert len(result) == world and all(all(v) for v in dict(result).values()), dict(result)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,cap,dist_kind", [(1, 700, "uniform"), (2, 900, "zipf"), (8, 120, "uniform"), (4, 2000, "zipf")])
+def test_slab_map_kernel_equals_its_numpy_restatement(P, cap, dist_kind):
+    """rec_shard_slab_map_uslot_i64 (message slabs, slot of every lookup, slot of every unique id) against
+    OracleBackend.slab_map on the same plan -- bit exact, incl. the tail of `uslot` (one row past the buffer)."""
+    from explicit_tf2_recommendation_amd import sharded
+    r = H.rng(7 + P)
+    V = 6000
+    rps = -(-V // P)
+    n = 900
+    a = r.integers(0, V, size=n) if dist_kind == "uniform" else np.minimum(r.zipf(1.2, size=n) - 1, V - 1)
+    # every owner within capacity: clip the id set if needed (the overflow flag is covered by the DeepFM step's tests)
+    ids = torch.from_numpy(a.astype(np.int64))
+    ref_plan = OracleBackend.plan(ids, V)
+    nu = int(ref_plan.n_uniq.item())
+    uniq = ref_plan.uniq_ids.numpy()[:nu]
+    per_owner = np.bincount(uniq // rps, minlength=P)
+    if per_owner.max() > cap:
+        pytest.skip("id sample exceeds the capacity of this case")
+    msg0, slot0, us0 = OracleBackend.slab_map(ref_plan, n, rps, P, cap, None)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    plan = sharded.HipBackend.plan(ids.cuda(), V)
+    msg, slot, us = sharded.HipBackend.slab_map(plan, n, rps, P, cap, flag)
+    assert int(flag.item()) == 0
+    assert torch.equal(slot.cpu(), slot0) and torch.equal(us.cpu(), us0)
+    m, m0 = msg.cpu().numpy(), msg0.numpy()
+    for o in range(P):
+        c = int(m0[o, 0])
+        assert m[o, 0] == c and np.array_equal(m[o, 2:2 + c], m0[o, 2:2 + c])
+    # the plan of the ids is the plan of the slots: slot[perm[seg_start[u]]] == uslot[u]
+    perm, seg = plan.perm.cpu().numpy(), plan.seg_start.cpu().numpy()
+    assert np.array_equal(slot0.numpy()[perm[seg[:nu]]], us0.numpy()[:nu])
