@@ -1000,12 +1000,41 @@ __global__ __launch_bounds__(256) void colseg_sum_kernel(ColSegArgs k) { colseg_
 // ---- direct mode: what is left for the launch after the fused kernel.  ONE LANE per run (slot) of the plan:
 //   a run of one lookup (almost all of them with uniform ids): g_w = gz of that lookup, uniq_ids = its id -- coalesced
 //     stores, the value row is already in place;
-//   a run of 2..8 lookups: the lane adds the other members' value rows to the head's row itself (position order);
-//   a longer run: the whole wave adds it, 16 members x 4 float4 chunks per round, fixed butterfly over the 16 rows;
+//   a pair: the lane adds the second member's value row to the head's row itself;
+//   a run of 3..FIX_SHORT lookups: four lanes (one 16-byte chunk each), 16 runs of the wave at a time, members in order;
+//   a run of up to FIX_HUGE: the whole wave adds it, 16 members x 4 float4 chunks per round, fixed butterfly over the rows;
+//   longer ones (Zipf heads): the whole workgroup, partial rows of its 16 waves added in wave order;
 //   slots beyond the column's runs: the zero-padded tail.
-// A wave takes 4 consecutive runs from each sixteenth of a column (when B is a multiple of 64), so that neighbouring
-// hot ids -- the synthetic Zipf draws make the smallest ids of a field the frequent ones -- fall to different waves.
-constexpr int FIX_T = 1024;
+constexpr int FIX_T = 1024, FIX_HUGE = 128, FIX_SHORT = 17, FIX_SKEW = 256;
+// slot t of a column (thread order) -> run u, twice.
+// fix_deal: the mapping of the FAST path (ids, single lookups, pairs, the padded tail -- nearly everything, and all of it
+// coalesced stores): a wave takes 4 consecutive runs from each sixteenth of the column, so that plan words arrive and ids
+// leave as 16-byte pieces, and a workgroup owns whole lines of uniq_ids / g_w.  (Interleaving the waves of different
+// workgroups here cost 2.3 us with uniform ids: every line of the outputs was then written in pieces by four CUs.)
+// fix_spread: the mapping under which the runs of MORE THAN TWO members are looked at a second time and summed: lane l of
+// the column's wave w takes run l * (B / 64) + w -- the hot ids of a field, neighbours at the head of the column with
+// the synthetic Zipf draws, fall to different waves (a wave adds its long runs one after the other).  Read-only plan
+// words, scattered row stores either way.
+__device__ __forceinline__ int fix_deal(int t, int64_t B) {
+  if ((B & 63) != 0) return t;
+  return ((t & 63) >> 2) * (int)(B >> 4) + 4 * (t >> 6) + (t & 3);
+}
+__device__ __forceinline__ int fix_spread(int t, int64_t B) {
+  if ((B & 63) != 0) return t;
+  return (t & 63) * (int)(B >> 6) + (t >> 6);
+}
+// lanes 4g .. 4g+3 get the lane index of the g-th set bit of mask (-1: fewer than g+1 bits).  mask is wave-uniform: the
+// scan runs on the scalar unit
+__device__ __forceinline__ int fix_group_src(unsigned long long mask, int lane) {
+  int src = -1;
+  const int g = lane >> 2;
+  for (int i = 0; i < 16 && mask; ++i) {
+    const int sl = __ffsll((long long)mask) - 1;
+    mask &= mask - 1;
+    if (g == i) src = sl;
+  }
+  return src;
+}
 __device__ __forceinline__ void fixup_body(const ColSegArgs& k_in, int bidx) {
   ColSegArgs k = k_in;
   if (k.lr_t_dev) k.lr_t = *k.lr_t_dev;
@@ -1018,13 +1047,16 @@ __device__ __forceinline__ void fixup_body(const ColSegArgs& k_in, int bidx) {
   const int per_col = (int)((B + FIX_T - 1) / FIX_T);           // workgroups per column
   const int f = bidx / per_col;
   const int t = (bidx - f * per_col) * FIX_T + tid;             // slot of the column before the deal
-  int u = t;
-  if ((B & 63) == 0) {
-    const int w = t >> 6, l = t & 63;
-    u = (l >> 2) * (int)(B >> 4) + 4 * w + (l & 3);
-  }
+  const int u = fix_deal(t, B);
   __shared__ int nu_s[REC_MAX_COLS];
+  // runs of more than FIX_HUGE members (Zipf heads: the hottest id of a column holds ~10 % of its lookups) are left to
+  // the WHOLE workgroup: at most B / FIX_HUGE <= 128 of them exist in a column
+  __shared__ int huge_n, huge_s0[128], huge_s1[128], huge_u[128];
+  __shared__ float huge_gz[128];
+  __shared__ float4 hpart[FIX_T / 64][4];
+  __shared__ float hw_s[FIX_T / 64];
   if (tid < F) nu_s[tid] = k.col_nu[tid];
+  if (tid == 0) huge_n = 0;
   __syncthreads();
   int64_t before = 0, total = 0;
   for (int q = 0; q < F; ++q) {
@@ -1044,24 +1076,23 @@ __device__ __forceinline__ void fixup_body(const ColSegArgs& k_in, int bidx) {
   const int len = s1 - s0;
   const int64_t dst = before + u;
   const bool adam = k.table != nullptr;
+  float accw = 0.f;                                             // gz of the run's head
   if (live) {
-    float accw = gz[pf[s0]];
+    accw = gz[pf[s0]];
     const int64_t id = k.col_uid[(int64_t)f * B + u];
-    if (len > 1 && len <= 8) {                                  // short run: this lane alone
+    if (len == 2) {                                             // a pair (nearly every multi-member run of a uniform batch):
+      const int64_t b2 = pf[s0 + 1];                            // this lane alone, two dependent round trips
+      const float4* r2 = vals + (b2 * F + f) * 4;
       float4 a0 = g_embed[dst * 4], a1 = g_embed[dst * 4 + 1], a2 = g_embed[dst * 4 + 2], a3 = g_embed[dst * 4 + 3];
-      for (int s = s0 + 1; s < s1; ++s) {
-        const int64_t b = pf[s];
-        const float4* r = vals + (b * F + f) * 4;
-        const float4 x0 = r[0], x1 = r[1], x2 = r[2], x3 = r[3];
-        a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
-        a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
-        a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w;
-        a3.x += x3.x; a3.y += x3.y; a3.z += x3.z; a3.w += x3.w;
-        accw += gz[b];
-      }
+      const float4 x0 = r2[0], x1 = r2[1], x2 = r2[2], x3 = r2[3];
+      a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
+      a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
+      a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w;
+      a3.x += x3.x; a3.y += x3.y; a3.z += x3.z; a3.w += x3.w;
       g_embed[dst * 4] = a0; g_embed[dst * 4 + 1] = a1; g_embed[dst * 4 + 2] = a2; g_embed[dst * 4 + 3] = a3;
+      k.g_w[dst] = accw + gz[b2];
     }
-    if (len <= 8) k.g_w[dst] = accw;
+    if (len == 1) k.g_w[dst] = accw;
     k.uniq_ids[dst] = id;
   } else if (in_col) {
     // padded tail: slot = total + rank among the column's unused slots; id = the smallest id of column 0, zero rows
@@ -1071,14 +1102,85 @@ __device__ __forceinline__ void fixup_body(const ColSegArgs& k_in, int bidx) {
     k.g_w[d2] = 0.f;
     k.uniq_ids[d2] = k.col_uid[0];
   }
-  // long runs, one at a time, by the whole wave: lane = (member slot r of 16, chunk c of 4)
-  unsigned long long longm = __ballot(live && len > 8);
+  // ---- runs of more than two members: the second look (fix_spread) -- for a column with more than FIX_SKEW lookups
+  // beyond the first of their runs; a column without (uniform ids: ~90 pairs) has next to nothing to balance, and the
+  // second look costs 1.3 us of scattered plan-word loads: its few longer runs are added where the fast path found them
+  const bool skew = B - nu > FIX_SKEW;                           // uniform over the workgroup
+  const int ub = skew ? fix_spread(t, B) : u;
+  int s0b = s0, s1b = s1;
+  if (skew) {
+    s0b = 0; s1b = 0;
+    if (in_col && ub < nu) {
+      s0b = k.col_seg[(int64_t)f * (B + 1) + ub];
+      s1b = k.col_seg[(int64_t)f * (B + 1) + ub + 1];
+    }
+  }
+  const int lenb = s1b - s0b;
+  float accwb = 0.f;                                            // gz of the run's head
+  if (lenb > 2) accwb = skew ? gz[pf[s0b]] : accw;
+  // (without skew the few runs of more than two members all take the whole-wave path below: no list, no barrier)
+  if (skew && lenb > FIX_HUGE) {                                 // (which entry a run gets does not matter: every run is
+    const int i = atomicAdd(&huge_n, 1);                         // summed on its own, in a fixed order)
+    if (i < 128) { huge_s0[i] = s0b; huge_s1[i] = s1b; huge_u[i] = ub; huge_gz[i] = accwb; }
+  }
   const int r = lane >> 2, c = lane & 3;
+  // runs of 3..FIX_SHORT members: FOUR lanes per run (one 16-byte chunk of the row each), 16 runs per round; head + member
+  // 2 + member 3 ... in member order, four members' loads in flight at a time.  (One lane per run walking its members
+  // paid two dependent round trips per member: up to 14 in a row for a run of 8 -- with Zipf ids every wave has a few.)
+  {
+    unsigned long long shortm = __ballot(skew && lenb > 2 && lenb <= FIX_SHORT);
+#ifdef ABL_NOSHORT
+    shortm = 0;
+#endif
+    while (shortm) {                                            // wave-uniform
+      const int src = fix_group_src(shortm, lane);
+      const bool has = src >= 0;
+      const int sl = has ? src : 0;
+      const int gs0 = __shfl(s0b, sl, 64), gs1_ = __shfl(s1b, sl, 64), gu = __shfl(ub, sl, 64);
+      float wsum = __shfl(accwb, sl, 64);
+      const int gs1 = has ? gs1_ : 0;                            // (the shuffles themselves need every lane)
+      const int64_t gdst = before + gu;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has) acc = g_embed[gdst * 4 + c];
+      for (int sp = gs0 + 1; __any(sp < gs1); sp += 4) {
+        if (sp < gs1) {
+          int e[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) e[j] = pf[sp + j < gs1 ? sp + j : gs1 - 1];
+          float4 xm[4];
+          float gm[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            xm[j] = vals[((int64_t)e[j] * F + f) * 4 + c];
+            gm[j] = gz[e[j]];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (sp + j < gs1) {
+              acc.x += xm[j].x; acc.y += xm[j].y; acc.z += xm[j].z; acc.w += xm[j].w;
+              wsum += gm[j];
+            }
+          }
+        }
+      }
+      if (has) {
+        g_embed[gdst * 4 + c] = acc;
+        if (c == 0) k.g_w[gdst] = wsum;
+      }
+      for (int i = 0; i < 16 && shortm; ++i) shortm &= shortm - 1;
+    }
+  }
+  // long runs, one at a time, by the whole wave: lane = (member slot r of 16, chunk c of 4)
+  unsigned long long longm = __ballot(skew ? (lenb > FIX_SHORT && lenb <= FIX_HUGE) : lenb > 2);
+#ifdef ABL_NOLONG
+  longm = 0;
+#endif
   while (longm) {
     const int src = __ffsll((long long)longm) - 1;
     longm &= longm - 1;
-    const int rs0 = __shfl(s0, src, 64), rs1 = __shfl(s1, src, 64);
-    const int ru = __shfl(u, src, 64);
+    const int rs0 = __shfl(s0b, src, 64), rs1 = __shfl(s1b, src, 64);
+    const int ru = __shfl(ub, src, 64);
+    const float rgz = __shfl(accwb, src, 64);
     const int64_t rdst = before + ru;
     float4 pa = make_float4(0.f, 0.f, 0.f, 0.f);
     float pw = 0.f;
@@ -1099,9 +1201,83 @@ __device__ __forceinline__ void fixup_body(const ColSegArgs& k_in, int bidx) {
       float4 h = g_embed[rdst * 4 + c];
       h.x += pa.x; h.y += pa.y; h.z += pa.z; h.w += pa.w;
       g_embed[rdst * 4 + c] = h;
-      const float wsum = gz[pf[rs0]] + pw;
+      const float wsum = rgz + pw;
       if (c == 0) k.g_w[rdst] = wsum;
     }
+  }
+  // huge runs, up to 16 at a time, by the whole workgroup: with n of them in a round, 16 / n waves share a run (wave of run
+  // h, sub-index sw: member slots 16 sw + r, stride 16 * waves-per-run, four members per lane in flight); the waves'
+  // partial rows meet in LDS and the run's first wave adds them in wave order.  (One wave walking the 848 members of a
+  // Zipf head 64 at a time was a 13-round dependent chain; the whole workgroup taking the huge runs one after the other
+  // still paid ~5 round trips per run: 16 us of the 34-us launch with Zipf ids.)
+  if (skew) __syncthreads();                                     // (uniform over the workgroup)
+#ifdef ABL_NOHUGE
+  const int n_huge = 0;
+#else
+  const int n_huge = skew ? (huge_n < 128 ? huge_n : 128) : 0;
+#endif
+  const int wv = tid >> 6;
+  constexpr int NWV_F = FIX_T / 64;
+  for (int h0 = 0; h0 < n_huge; h0 += NWV_F) {
+    const int nr = n_huge - h0 < NWV_F ? n_huge - h0 : NWV_F;    // runs of this round
+    const int wpr = NWV_F / nr;                                  // waves per run
+    const int hl = wv / wpr, sw = wv - hl * wpr;
+    const bool mine = hl < nr;
+    const int h = h0 + (mine ? hl : 0);
+    const int rs0 = huge_s0[h], rs1 = mine ? huge_s1[h] : 0;
+    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f);
+    float pw = 0.f;
+    const int stride = 16 * wpr;
+    // four members per lane and round in flight (eight cost 25 more registers: at 81 the launch dropped to one workgroup
+    // per CU and the uniform step lost 0.7 us)
+    for (int base = rs0 + 1 + 16 * sw + r; base < rs1; base += 4 * stride) {
+      int bm[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int sidx = base + j * stride;
+        bm[j] = pf[sidx < rs1 ? sidx : rs1 - 1];
+      }
+      float4 xm[4];
+      float gm[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xm[j] = vals[((int64_t)bm[j] * F + f) * 4 + c];
+        gm[j] = gz[bm[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (base + j * stride < rs1) {
+          pa.x += xm[j].x; pa.y += xm[j].y; pa.z += xm[j].z; pa.w += xm[j].w;
+          pw += gm[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) {
+      pa.x += __shfl_xor(pa.x, o, 64); pa.y += __shfl_xor(pa.y, o, 64);
+      pa.z += __shfl_xor(pa.z, o, 64); pa.w += __shfl_xor(pa.w, o, 64);
+      pw += __shfl_xor(pw, o, 64);
+    }
+    float4 hsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t rdst = before + huge_u[h];
+    const bool fin = mine && sw == 0 && r == 0;                  // the run's first wave, one lane per chunk
+    if (fin) hsum = g_embed[rdst * 4 + c];                       // (in flight across the barrier)
+    if (r == 0) {
+      hpart[wv][c] = pa;
+      if (c == 0) hw_s[wv] = pw;
+    }
+    __syncthreads();
+    if (fin) {
+      float wsum = huge_gz[h];
+      for (int q = 0; q < wpr; ++q) {
+        const float4 x = hpart[wv + q][c];
+        hsum.x += x.x; hsum.y += x.y; hsum.z += x.z; hsum.w += x.w;
+        wsum += hw_s[wv + q];
+      }
+      g_embed[rdst * 4 + c] = hsum;
+      if (c == 0) k.g_w[rdst] = wsum;
+    }
+    __syncthreads();
   }
   if (bidx == 0 && tid == 0) *k.n_uniq = total;
   // The optimizer, once every row sum of this workgroup's slots is final: 8 lanes per row -- lanes 0..3 one 16-byte
@@ -1112,23 +1288,26 @@ __device__ __forceinline__ void fixup_body(const ColSegArgs& k_in, int bidx) {
     __syncthreads();
     const int piece = tid & 7, rr = tid >> 3;
     const int step_now = k.last ? (int32_t)*k.step_dev : 0;
+    // a row is updated by the workgroup that made its sum final: runs of up to two members under the fast mapping, longer
+    // ones under the spread mapping (another workgroup may still be adding those of this one's fast slots)
+    const bool skew_a = B - nu > FIX_SKEW;
 #pragma unroll 1
-    for (int p = 0; p < FIX_T / 128; ++p) {
-      const int tl = (bidx - f * per_col) * FIX_T + p * 128 + rr;
-      int uu = tl;
-      if ((B & 63) == 0) {
-        const int w2 = tl >> 6, l2 = tl & 63;
-        uu = (l2 >> 2) * (int)(B >> 4) + 4 * w2 + (l2 & 3);
-      }
+    for (int p = 0; p < (skew_a ? 2 : 1) * (FIX_T / 128); ++p) {
+      const bool spread = p >= FIX_T / 128;
+      const int tl = (bidx - f * per_col) * FIX_T + (spread ? p - FIX_T / 128 : p) * 128 + rr;
+      const int uu = spread ? fix_spread(tl, B) : fix_deal(tl, B);
       if (tl < B && uu < nu && piece < 5) {
-        const int64_t d2 = before + uu;
-        const int64_t id = k.col_uid[(int64_t)f * B + uu];
-        if ((uint64_t)id < (uint64_t)k.V) {
-          if (piece < 4) {
-            adam_chunk(k, id, piece, g_embed[d2 * 4 + piece]);
-          } else {
-            adam_w(k, id, k.g_w[d2]);
-            if (k.last) k.last[id] = step_now;
+        const int ln = k.col_seg[(int64_t)f * (B + 1) + uu + 1] - k.col_seg[(int64_t)f * (B + 1) + uu];
+        if (!skew_a || (ln > 2) == spread) {
+          const int64_t d2 = before + uu;
+          const int64_t id = k.col_uid[(int64_t)f * B + uu];
+          if ((uint64_t)id < (uint64_t)k.V) {
+            if (piece < 4) {
+              adam_chunk(k, id, piece, g_embed[d2 * 4 + piece]);
+            } else {
+              adam_w(k, id, k.g_w[d2]);
+              if (k.last) k.last[id] = step_now;
+            }
           }
         }
       }
@@ -1136,7 +1315,7 @@ __device__ __forceinline__ void fixup_body(const ColSegArgs& k_in, int bidx) {
   }
 }
 
-__global__ __launch_bounds__(1024) void deepfm_post_direct_kernel(ReduceArgs r, ColSegArgs k, int nb_reduce) {
+__global__ __launch_bounds__(1024, 8) void deepfm_post_direct_kernel(ReduceArgs r, ColSegArgs k, int nb_reduce) {
   if ((int)blockIdx.x < nb_reduce) reduce_body(r, (int)blockIdx.x);
   else fixup_body(k, (int)blockIdx.x - nb_reduce);
 }
