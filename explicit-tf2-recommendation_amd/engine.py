@@ -808,18 +808,29 @@ class HipStepBackend:
         self.col_lo = torch.tensor([int(o) for o in field_offsets], **i64)
         self.bad_ids = torch.zeros(1, **i32)
         self.o_ws_bytes = lib.rec_dedup_workspace_bytes(m)
-        self.plans = [dict(perm=torch.empty((F, B), **i32), col_uid=torch.empty((F, B), **i64),
-                           col_seg=torch.empty((F, B + 1), **i32), col_nu=torch.zeros(F, **i32),
+        # NPL plan buffers.  The eager step alternates between the first two (the plan of batch k+1 is built beside step
+        # k); many() gives every batch of its cycle a buffer of its own and sorts GROUP batches per launch -- the sort
+        # arrays of consecutive buffers are contiguous, so ONE rec_colsort_plan_i64 call over GROUP*F columns fills them
+        # (a sort workgroup cannot share a CU with a fused-kernel workgroup -- LDS --, so a 32-us sort per step was 32 us
+        # on the step's critical path; eight batches per launch cost ~36)
+        self.NPL = NPL = 16
+        self.GROUP = max(1, min(8, 256 // F))
+        self.col_lo_rep = self.col_lo.repeat(self.GROUP).contiguous()
+        self._perm = torch.empty((NPL, F, B), **i32)
+        self._col_uid = torch.empty((NPL, F, B), **i64)
+        self._col_seg = torch.empty((NPL, F, B + 1), **i32)
+        self._col_nu = torch.zeros((NPL, F), **i32)
+        self.plans = [dict(perm=self._perm[b], col_uid=self._col_uid[b], col_seg=self._col_seg[b], col_nu=self._col_nu[b],
                            msg=torch.zeros((P, cap + 2), **i64), msg_theirs=torch.zeros((P, cap + 2), **i64),
                            uidx=torch.empty((F, B), **i64), slot_map=torch.zeros(n, **i32), n_uniq=torch.zeros(1, **i64),
                            # owner side: union of the P lists that arrive (depends on ids only: built with the plan)
                            o_uniq=torch.empty(m, **i64), o_seg=torch.empty(m + 1, **i32), o_perm=torch.empty(m, **i32),
-                           o_nu=torch.zeros(1, **i64)) for _ in range(2)]
+                           o_nu=torch.zeros(1, **i64)) for b in range(NPL)]
         for pl in self.plans:
             pl["uidx_arr"] = (C.c_void_p * F)(*[pl["uidx"][f].data_ptr() for f in range(F)])
-        self.sort_ws = [torch.empty(lib.rec_colsort_workspace_bytes(B, F), dtype=torch.uint8, device=dev)
-                        for _ in range(2)]
-        self.o_ws = [torch.empty(self.o_ws_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.sort_ws = [torch.empty(lib.rec_colsort_workspace_bytes(B, F * self.GROUP), dtype=torch.uint8, device=dev)
+                        for _ in range(NPL)]
+        self.o_ws = [torch.empty(self.o_ws_bytes, dtype=torch.uint8, device=dev) for _ in range(NPL)]
         # every pointer below is fixed for the life of the step: the ctypes argument tuples are built once
         for buf, pl in enumerate(self.plans):
             pl["a_sort"] = (_p(self.col_lo), self.max_key, _p(pl["perm"]), _p(pl["col_uid"]), _p(pl["col_seg"]),
@@ -879,6 +890,22 @@ class HipStepBackend:
         check(lib.rec_colsort_plan_i64(self._col_arr(cols), F, B, st_.V, *pl["a_sort"], st), "rec_colsort_plan_i64")
         check(lib.rec_colsort_shard_map_fixed_i64(*pl["a_map"], st), "rec_colsort_shard_map_fixed_i64")
         return pl
+
+    def plan_group(self, cols_list, first_buf, on_side=False):
+        """The plans of len(cols_list) <= GROUP batches into the consecutive buffers first_buf, first_buf + 1, ...: ONE
+        per-column sort over all their columns, then the exchange map of each."""
+        st_ = self.step
+        B, F, k = st_.B, st_.F, len(cols_list)
+        assert 1 <= k <= self.GROUP and first_buf + k <= self.NPL
+        st = self.side_st if on_side else self.st
+        arr = (C.c_void_p * (k * F))(*[c.data_ptr() for cols in cols_list for c in cols])
+        pl = self.plans[first_buf]
+        check(lib.rec_colsort_plan_i64(arr, k * F, B, st_.V, _p(self.col_lo_rep), self.max_key, _p(pl["perm"]),
+                                       _p(pl["col_uid"]), _p(pl["col_seg"]), _p(pl["col_nu"]), _p(self.bad_ids),
+                                       _p(self.sort_ws[first_buf]), st), "rec_colsort_plan_i64")
+        for j in range(k):
+            check(lib.rec_colsort_shard_map_fixed_i64(*self.plans[first_buf + j]["a_map"], st),
+                  "rec_colsort_shard_map_fixed_i64")
 
     def owner_plan(self, pl, buf, on_side=False):
         """Union of the P ascending id lists that arrived (rank merge) as a segment plan over the payload rows."""
@@ -1094,6 +1121,12 @@ class ShardedDeepFMStep:
             with be.side_context():                          # C1 of the next batch: own communicator, second stream
                 nxt = self._plan(next_cols, 1 - buf, True)
             self._next = (next_key, 1 - buf, nxt)
+        return self._body(pl, y)
+
+    def _body(self, pl, y):
+        """What of a step needs the batch's plan to be complete: owner gather, C2, fused kernel, local sums, C3, owner sums,
+        C4."""
+        be, comm = self.be, self.comm
         rows_out = be.gather(self.table_shard, pl)                             # owner-side gather of 128-B rows
         rows_local = comm.exchange(rows_out, be.rows_local)                    # C2: [P*cap, 32], row = owner*cap + slot
         vals, gz = be.rows_step(pl, rows_local, y)
@@ -1116,10 +1149,36 @@ class ShardedDeepFMStep:
         graphs = self.__dict__.setdefault("_graphs", {})
         g = graphs.get(key)
         if g is None:
+            grouped = isinstance(self.be, HipStepBackend) and len(batches) <= self.be.NPL
+
             def run():
                 self._next = None
-                for i, b in enumerate(batches):
-                    self(b, label_name, next_inputs=batches[i + 1] if i + 1 < len(batches) else None)
+                if not grouped:
+                    for i, b in enumerate(batches):
+                        self(b, label_name, next_inputs=batches[i + 1] if i + 1 < len(batches) else None)
+                    return
+                # every plan of the cycle on the second stream, GROUP batches per sort launch (ids only: nothing of the
+                # steps is needed), each followed by its C1 and the owner's merge; step i waits for plan i alone
+                be, comm = self.be, self.comm
+                be.begin()
+                colss = [self._cols_key(b)[0] for b in batches]
+                ys = [self._label(b, label_name) for b in batches]
+                be.fork()
+                evs = []
+                with be.side_context():
+                    for j0 in range(0, len(batches), be.GROUP):
+                        be.plan_group(colss[j0:j0 + be.GROUP], j0, on_side=True)
+                    for i in range(len(batches)):
+                        pl = be.plans[i]
+                        pl["msg_theirs"] = comm.exchange_ids(pl["msg"], pl["msg_theirs"])
+                        be.owner_plan(pl, i, on_side=True)
+                        ev = torch.cuda.Event()
+                        ev.record(be.side)
+                        evs.append(ev)
+                for i in range(len(batches)):
+                    be.main.wait_event(evs[i])
+                    self._body(be.plans[i], ys[i])
+                be.join()
             run()                                            # communicators and lazy initialisation: not captured
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
