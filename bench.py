@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--sharded", action="store_true", help="force the row-sharded step (the default for N > 1) at N = 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
-    ap.add_argument("--adam-steps", type=int, default=10, help="extra: full train steps with reference-exact Adam")
+    ap.add_argument("--adam-steps", type=int, default=10, help="extra: full train steps with Keras Adam as the reference applies it (dense sweep)")
     return ap.parse_args()
 
 

@@ -53,7 +53,7 @@ def _tables_share_rows(embed, w):
 class DeepFMTrainStep:
     """fwd + bwd (+ optimizer) of DeepFMRankingLayer (2.FM/CustomLayers.py:279-308) under the reference's loss.
 
-    optimizer: None (gradients only -- the 'fwd+bwd' of the headline metric), 'keras_adam' (reference-exact:
+    optimizer: None (gradients only -- the 'fwd+bwd' of the headline metric), 'keras_adam' (the reference's semantics:
     dense sweep over the tables) or 'lazy_adam' (touched rows only; NOT the reference's semantics).
     """
 

@@ -22,7 +22,7 @@ from . import ops
 class KerasAdam:
     """tf.keras.optimizers.Adam(learning_rate) (2.FM/ModelManager.py:104) on the HIP kernels: dense parameters get
     the dense apply; tables get the Keras SPARSE apply, which decays m, v and moves var on ALL rows every step
-    (``sparse_mode='keras'``, reference-exact) or the touched rows only (``'lazy'``, not the reference)."""
+    (``sparse_mode='keras'``, the reference's semantics; fp32 within an ulp of x per step of a correctly rounded evaluation, see csrc/common.h) or the touched rows only (``'lazy'``, not the reference)."""
 
     def __init__(self, params, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, sparse_mode="keras"):
         self.params = list(params)
