@@ -362,6 +362,7 @@ class DeepFMFusedStep:
         # (stream priorities were tried for keeping the plan sorts out of the step's way: the range is (0, -1), the default 0
         # is already the lowest, and a step enqueued on a priority -1 stream ran 2.5x SLOWER from its graphs)
         self.side_stream = torch.cuda.Stream(device=dev)
+        self._advanced = False                               # the fused launch of the step in flight advanced the step counter
         if optimizer is not None:
             self.state = {name: (torch.zeros(p.shape, **f32), torch.zeros(p.shape, **f32))
                           for name, p in layer.named_parameters()}
@@ -518,7 +519,7 @@ class DeepFMFusedStep:
             params = dict(self.layer.named_parameters())
             pe = params["embed.embeddings"]
             (me, ve), (mw, vw) = self.state["embed.embeddings"], self.state["w.embeddings"]
-            if not getattr(self, "_advanced", False):        # (the v3 fused launch has already advanced the counter)
+            if not self._advanced:                           # (the v3 fused launch has already advanced the counter)
                 check(lib.rec_adam_advance_f32(_p(self._step_dev), _p(self._lr_tab), self._lr_tab.numel(),
                                                _p(self._lr_t_dev), st), "rec_adam_advance_f32")
             self._advanced = False

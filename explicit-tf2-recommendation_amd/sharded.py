@@ -10,7 +10,10 @@ so all-to-all is the natural collective (one hop, all 7 links busy).
               C1  all-to-all of fixed-capacity id slabs (no count exchange, nothing read back by the host)
               --  local gather on the owner (HIP gather kernel)
               C2  all-to-all of the gathered rows back to the requesters (row = owner*cap + rank: no permutation)
-    backward  C3  all-to-all of the per-unique-id row gradients to the owners, who add the P ascending lists
+    backward  --  ONE segment sum of the consumers' gradient rows in the order of the forward's plan (the slot is monotone
+                  in the id: the plan of the ids is the plan of the slots), laid out dense by slot
+              C3  all-to-all of the per-unique-id row gradients to the owners, who add the P ascending lists
+                  (world size 1: no collective, no merge)
 
 The integer side (bucketize / permutation / counts) is bit exact and independent of P; tests/test_sharded.py holds
 ``lookup == table[ids]`` bitwise for P in {1,2,4,8} logical shards on one device and for a 2-rank gloo group.
