@@ -420,8 +420,12 @@ def main():
     # before the opening barrier: (1) no graph is captured inside the timed region whatever K is; (2) the GPU goes into it
     # busy -- after an idle stretch (the 45-ms collection above is one) the first ~150 us of work run at idle clocks,
     # which at K = 20 is a tenth of the region.
-    for _ in range(4):       # a graph is captured at the SECOND sighting of a call's addresses, and every call has two
-        run_steps(args.steps)    # forms (the plan-buffer ring has two halves): four rehearsals leave nothing to capture
+    # a graph is captured at the SECOND sighting of a call's addresses (that call itself still runs eagerly) and every call
+    # has two forms (the plan-buffer ring has two halves): four rehearsals leave nothing to capture, and two more REPLAY
+    # each captured graph once -- the first launch of a graph uploads it (40-500 us once per graph, which at K = 20 was
+    # 2-25 us per step of the first timed region)
+    for _ in range(6):
+        run_steps(args.steps)
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps)
@@ -627,7 +631,7 @@ def main():
                 zstep.many(cur, then=nxt)
 
         zrun(2 * n_batches)
-        for _ in range(4):
+        for _ in range(6):
             zrun(args.steps)
         zt = []
         for _ in range(5):
@@ -637,6 +641,27 @@ def main():
             barrier()
             zt.append((time.perf_counter() - t1) / args.steps)
         zstep.check_flags()
+        # ... and on four more draws of the uniform ids (seeds 0..4; `value` is seed 0): the same graphs'
+        # worth of work on other addresses, median of three regions each
+        seeds = {}
+        for sd in (1, 2, 3, 4):
+            gs_ = data.SyntheticGenerator(names, V, dist=args.dist, seed=1000 * sd + rank)
+            sb = [data.to_device(gs_.batch(B)) for _ in range(n_batches)]
+            for _ in range(6):
+                for cur, nxt in calls_of(args.steps, sb):
+                    zstep.many(cur, then=nxt)
+            st_ = []
+            for _ in range(3):
+                barrier()
+                t1 = time.perf_counter()
+                for cur, nxt in calls_of(args.steps, sb):
+                    zstep.many(cur, then=nxt)
+                barrier()
+                st_.append((time.perf_counter() - t1) / args.steps)
+            seeds[str(sd)] = float(np.median(st_)) * 1e3
+            del sb
+        zstep.check_flags()
+        extra["ms_per_step_seeds_1_to_4"] = seeds
         extra["value_zipf"] = world * B / float(np.median(zt))
         extra["ms_per_step_zipf"] = float(np.median(zt)) * 1e3
         del zb, zstep
