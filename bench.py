@@ -642,7 +642,7 @@ def main():
             zt.append((time.perf_counter() - t1) / args.steps)
         zstep.check_flags()
         # ... and on four more draws of the uniform ids (seeds 0..4; `value` is seed 0): the same graphs'
-        # worth of work on other addresses, median of three regions each
+        # worth of work on other addresses, median of five regions each
         seeds = {}
         for sd in (1, 2, 3, 4):
             gs_ = data.SyntheticGenerator(names, V, dist=args.dist, seed=1000 * sd + rank)
@@ -651,7 +651,7 @@ def main():
                 for cur, nxt in calls_of(args.steps, sb):
                     zstep.many(cur, then=nxt)
             st_ = []
-            for _ in range(3):
+            for _ in range(5):
                 barrier()
                 t1 = time.perf_counter()
                 for cur, nxt in calls_of(args.steps, sb):
