@@ -359,9 +359,10 @@ class DeepFMFusedStep:
         self.g_w_rows = torch.empty((n, 1), **f32)
         self.n_uniq = torch.zeros(1, dtype=torch.int64, device=dev)
         self.sort_ws = torch.empty(lib.rec_colsort_workspace_bytes(B, F * self.GROUP), dtype=torch.uint8, device=dev)
-        # (stream priorities were tried for keeping the plan sorts out of the step's way: the range is (0, -1), the default 0
-        # is already the lowest, and a step enqueued on a priority -1 stream ran 2.5x SLOWER from its graphs)
-        self.side_stream = torch.cuda.Stream(device=dev)
+        # (the plan sorts run on the caller's stream behind the steps of a call.  A second stream was tried at every
+        # priority the device offers -- the range is (0, -1), the default 0 is the lowest, and a step enqueued on a
+        # priority -1 stream ran 2.5x SLOWER from its graphs: a sort workgroup cannot share a CU with a fused-kernel
+        # workgroup, so concurrency only moved the wait into one fused launch in eight)
         self._advanced = False                               # the fused launch of the step in flight advanced the step counter
         if optimizer is not None:
             self.state = {name: (torch.zeros(p.shape, **f32), torch.zeros(p.shape, **f32))
@@ -670,19 +671,12 @@ class DeepFMFusedStep:
         gkey = (tuple(keys), tuple(y.data_ptr() for _, y in seq), tuple(then_keys), tuple(bufs), tuple(inline))
 
         def enqueue_all():
-            main, side = torch.cuda.current_stream(), self.side_stream
+            main = torch.cuda.current_stream()
             st = C.c_void_p(main.cuda_stream)
-            for i in inline:                                     # not announced: sorted in line, all of them BEFORE the
-                self._sort(seq[i][0], bufs[i], main)             # second stream starts (the sorts share one workspace)
-            if then_cols:
-                start_ev = torch.cuda.Event()
-                start_ev.record(main)                            # a sort only needs ids: nothing of this call
+            for i in inline:                                     # not announced: sorted in line
+                self._sort(seq[i][0], bufs[i], main)
             self._row = 0
-            self._launch_main(seq[0][0], seq[0][1], st, bufs[0])  # the critical path's first kernel goes first
-            if then_cols:
-                side.wait_event(start_ev)
-                for j in range(0, len(then_cols), self.GROUP):   # GROUP batches (consecutive buffers) per sort call
-                    self._sort_group(then_cols[j:j + self.GROUP], then_bufs[j], side)
+            self._launch_main(seq[0][0], seq[0][1], st, bufs[0])
             for i in range(n):
                 self._row = i
                 if i > 0:
@@ -691,8 +685,13 @@ class DeepFMFusedStep:
                 self._launch_post(bufs[i], st, t)
                 if self.optimizer is not None:
                     self._optimizer(t, st)
-            if then_cols:
-                main.wait_stream(side)                           # join: the next call relies on the other half
+            # the plans of the batches announced for the NEXT call: GROUP batches (consecutive buffers) per sort launch, on the
+            # main stream BEHIND this call's steps.  (They used to run on a second stream beside the steps -- but a sort
+            # workgroup cannot share a CU with a fused-kernel workgroup (LDS), so "beside" meant that one fused launch in
+            # eight waited for the sort: serial on one stream is 0.7 us per step faster at K = 200, the same at K = 20, and
+            # the graph has no fork / join.)
+            for j in range(0, len(then_cols), self.GROUP):
+                self._sort_group(then_cols[j:j + self.GROUP], then_bufs[j], main)
 
         t_base = self.t
         if self.kernel_version >= 3:
