@@ -347,7 +347,9 @@ class DeepFMFusedStep:
                            col_nu=self._col_nu[b], dloc=self._dloc[b]) for b in range(NB)]
         # consecutive buffers are contiguous, so ONE sort call can build the plans of GROUP upcoming batches as
         # GROUP*F columns (the sort kernels are latency-bound at < 1 wave per SIMD: two batches cost ~1.2x one)
-        self.GROUP = max(1, min(8, 256 // F))
+        # (256 column pointers per sort launch: one workgroup per column, and a CU holds ONE sort workgroup (86 KB of LDS) --
+        # 17 batches per launch, 442 workgroups, were measured slower than 9)
+        self.GROUP = max(1, 256 // F)
         self.col_lo_rep = self.col_lo.repeat(self.GROUP).contiguous()
         self._prefetched, self._half = {}, 0     # plans announced by the previous call: id-tensor addresses -> buffer
         self._col_cache = {}
@@ -690,8 +692,12 @@ class DeepFMFusedStep:
             # workgroup cannot share a CU with a fused-kernel workgroup (LDS), so "beside" meant that one fused launch in
             # eight waited for the sort: serial on one stream is 0.7 us per step faster at K = 200, the same at K = 20, and
             # the graph has no fork / join.)
-            for j in range(0, len(then_cols), self.GROUP):
-                self._sort_group(then_cols[j:j + self.GROUP], then_bufs[j], main)
+            m_ = len(then_cols)
+            if m_:
+                nl = -(-m_ // self.GROUP)                        # as few launches as the column limit allows, evenly filled
+                per = -(-m_ // nl)
+                for j in range(0, m_, per):
+                    self._sort_group(then_cols[j:j + per], then_bufs[j], main)
 
         t_base = self.t
         if self.kernel_version >= 3:
