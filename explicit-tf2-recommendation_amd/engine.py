@@ -271,8 +271,8 @@ def _bits(n):
 class DeepFMFusedStep:
     """The same train_loop iteration as DeepFMTrainStep in two launches on the main stream (csrc/deepfm_fused.hip):
     the fused forward+backward kernel, then ONE launch for the fixed-order reduction of its partials and the segment
-    sums -- plus the per-column LDS sort of the de-duplication plan of upcoming batches on a second stream (it depends
-    only on the ids).  ``many()`` runs several iterations as one captured hipGraph.
+    sums -- plus, behind the steps of a call, the per-column LDS sort of the de-duplication plans of the batches announced
+    for the next call (they depend only on the ids).  ``many()`` runs several iterations as one captured hipGraph.
 
     Requirements (checked; otherwise use DeepFMTrainStep): embedding_dims 16, mlp_dims [32,8], fused table layout,
     F <= 28, B <= 16384, and the DataGenerator id-space contract -- ``field_offsets[f]``/``field_dims[f]`` =
@@ -333,10 +333,9 @@ class DeepFMFusedStep:
             "bias": torch.empty(1, **f32),
         }
         self.ws = torch.empty(lib.rec_deepfm_fused_workspace_bytes(B, F), dtype=torch.uint8, device=dev)
-        # NBUF plan buffers: the de-duplication plan depends on the ids only, so the plan of batch k+1 is built (second
-        # stream) while batch k is being differentiated.  Inside a multi-step graph of fewer than NBUF steps every batch
-        # has a buffer of its own, so no sort ever has to wait for an earlier step to release one: the sort chains
-        # depend on nothing but each other and run ahead on the second stream
+        # NBUF plan buffers: the de-duplication plan depends on the ids only, so the plans of the NEXT call's batches are
+        # built behind the steps of this call.  Every batch of a call has a buffer of its own (two halves of NBUF / 2 used
+        # alternately: one is read by this call's steps while the other is filled for the next call)
         NB = self.NBUF
         self._perm = torch.empty((NB, F, B), dtype=torch.int32, device=dev)
         self._col_uid = torch.empty((NB, F, B), dtype=torch.int64, device=dev)
@@ -600,8 +599,8 @@ class DeepFMFusedStep:
 
     def __call__(self, inputs, label_name="label", next_inputs=None):
         """One train_loop iteration on `inputs`.  ``next_inputs`` (optional) = the batch of the NEXT call: its
-        de-duplication plan is built on the second stream while this batch is differentiated (input-pipeline style
-        prefetch: the plan depends on ids only).  Without it, or when the previous call did not announce this batch,
+        de-duplication plan is built behind this call's step (input-pipeline style prefetch: the plan depends on ids
+        only).  Without it, or when the previous call did not announce this batch,
         the plan is built inside this call, in front of the fused kernel."""
         return self.many([inputs], label_name, then=next_inputs)
 
@@ -626,8 +625,9 @@ class DeepFMFusedStep:
     def many(self, batches, label_name="label", then=None):
         """len(batches) consecutive train_loop iterations; with ``use_graph`` as ONE hipGraph replay (a launch-bound
         inner loop: one graph launch costs ~20 us of idle GPU).  ``then``: the batch, or the list of batches, of the NEXT
-        call -- their de-duplication plans are built on the second stream beside this call's steps, so that no fused
-        kernel of the next call waits for a sort (the plan has to be complete before the kernel starts: direct mode).
+        call -- their de-duplication plans are built behind this call's steps, several batches per sort launch, so that
+        no fused kernel of the next call waits for a sort (the plan has to be complete before the kernel starts: direct
+        mode).
         A batch of this call that no earlier call announced is sorted in line.  Results left in the buffers are the last
         step's; gradients are to be consumed by an optimizer in the same call or after single-step calls."""
         half = self.NBUF // 2
